@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_f{32,64}.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+ENTRY_DIST_UNIFORM = 1
+ENTRY_DIST_OCCUPANCY = 2
+NCODES = 1364
+
+R_STATE, S_STATE, N_STATE, B_STATE, E_STATE, J_STATE, C_STATE, T_STATE = (
+    (3 << 14) | i for i in range(8))
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle_f32.so")
+    src = os.path.join(ORACLE_DIR, "oracle.c")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def encode(seq: str) -> bytes:
+    """ACGT text -> symbol ids 0..3 (imm_dna_iupac order)."""
+    return bytes("ACGT".index(c) for c in seq)
+
+
+class Profile:
+    def __init__(self, orc, handle):
+        self.orc = orc
+        self.h = handle
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_profile_del(self.h)
+        except Exception:
+            pass
+
+    @property
+    def core_size(self):
+        return self.orc.lib.orc_profile_core_size(self.h)
+
+    def setup(self, L, multi_hits=True, hmmer3_compat=False):
+        return self.orc.lib.orc_profile_setup(self.h, L, int(multi_hits), int(hmmer3_compat))
+
+    def viterbi(self, alt, seq: bytes, want_path=True):
+        o = self.orc
+        ll = o.fl()
+        cap = 2 * len(seq) + 3 * self.core_size + 16
+        n = C.c_uint(cap)
+        if want_path:
+            st = np.zeros(cap, np.uint16)
+            ln = np.zeros(cap, np.uint8)
+            rc = o.lib.orc_viterbi(self.h, int(alt), seq, len(seq), C.byref(ll),
+                                   st.ctypes.data, ln.ctypes.data, C.byref(n))
+            return rc, ll.value, list(zip(st[:n.value].tolist(), ln[:n.value].tolist()))
+        rc = o.lib.orc_viterbi(self.h, int(alt), seq, len(seq), C.byref(ll), None, None, C.byref(n))
+        return rc, ll.value, None
+
+    def viterbi_fast(self, seq: bytes):
+        o = self.orc
+        nl, al = o.fl(), o.fl()
+        rc = o.lib.orc_viterbi_fast(self.h, seq, len(seq), C.byref(nl), C.byref(al))
+        return rc, nl.value, al.value
+
+    def export(self):
+        """(trans8 [8,M], emis_match [1364,M], emis_insert, emis_null, xtrans[13])"""
+        o, M = self.orc, self.core_size
+        t8 = np.zeros((8, M), o.np)
+        em = np.zeros((NCODES, M), o.np)
+        ei = np.zeros(NCODES, o.np)
+        en = np.zeros(NCODES, o.np)
+        xt = np.zeros(13, o.np)
+        o.lib.orc_profile_export(self.h, t8.ctypes.data, em.ctypes.data, ei.ctypes.data,
+                                 en.ctypes.data, xt.ctypes.data)
+        return t8, em, ei, en, xt
+
+    def dists(self):
+        """(null [129], insert [129], match [M,129]) as nucltp[4] + codonm[125]."""
+        o, M = self.orc, self.core_size
+        nd = np.zeros(129, o.np)
+        idd = np.zeros(129, o.np)
+        md = np.zeros((M, 129), o.np)
+        o.lib.orc_profile_dists(self.h, nd.ctypes.data, idd.ctypes.data, md.ctypes.data)
+        return nd, idd, md
+
+    def decode(self, frag: bytes, state_id: int):
+        cod = C.create_string_buffer(3)
+        lp = self.orc.lib.orc_profile_decode(self.h, frag, len(frag), state_id, cod)
+        return lp, "".join("ACGT"[b] if b < 4 else "X" for b in cod.raw[:3])
+
+
+class Oracle:
+    def __init__(self, bits=32):
+        build_oracle()
+        self.bits = bits
+        self.fl = C.c_double if bits == 64 else C.c_float
+        self.np = np.float64 if bits == 64 else np.float32
+        lib = C.CDLL(os.path.join(ORACLE_DIR, f"liboracle_f{bits}.so"))
+        fl = self.fl
+        lib.orc_profile_sample.restype = C.c_void_p
+        lib.orc_profile_sample.argtypes = [C.c_uint, C.c_uint, C.c_int, fl]
+        lib.orc_profile_new.restype = C.c_void_p
+        lib.orc_profile_new.argtypes = [C.c_uint, C.c_int, fl, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_profile_del.argtypes = [C.c_void_p]
+        lib.orc_profile_core_size.argtypes = [C.c_void_p]
+        lib.orc_profile_core_size.restype = C.c_uint
+        lib.orc_profile_nstates.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_profile_nstates.restype = C.c_uint
+        lib.orc_profile_setup.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int]
+        lib.orc_profile_export.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        lib.orc_profile_dists.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+        lib.orc_viterbi.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint, C.POINTER(fl),
+                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+        lib.orc_viterbi_fast.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.POINTER(fl), C.POINTER(fl)]
+        lib.orc_dp_tables.argtypes = [C.c_uint, C.c_uint] + [C.c_void_p] * 5 + [
+            C.c_char_p, C.c_uint, C.POINTER(fl), C.POINTER(fl)]
+        lib.orc_profile_decode.restype = fl
+        lib.orc_profile_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_uint, C.c_char_p]
+        lib.orc_state_name.argtypes = [C.c_uint, C.c_char_p]
+        lib.orc_lrt.restype = fl
+        lib.orc_lrt.argtypes = [fl, fl]
+        lib.orc_logaddexp.restype = fl
+        lib.orc_logaddexp.argtypes = [fl, fl]
+        lib.orc_frame_table.argtypes = [C.c_void_p, fl, C.c_void_p]
+        lib.orc_setup_nuclt_dist.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_scan.restype = C.c_long
+        lib.orc_scan.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_uint, C.c_int,
+                                 C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orc_rnd_seed.argtypes = [C.c_void_p, C.c_uint64]
+        lib.orc_rnd_dbl.restype = C.c_double
+        lib.orc_rnd_dbl.argtypes = [C.c_void_p]
+        self.lib = lib
+
+    def sample(self, seed, core_size, entry_dist=ENTRY_DIST_OCCUPANCY, epsilon=0.01):
+        eps = float(np.float32(epsilon))  # cfg literals are floats: protein_cfg(…, 0.1f)
+        h = self.lib.orc_profile_sample(seed, core_size, entry_dist, eps)
+        assert h
+        return Profile(self, h)
+
+    def new(self, null_lprobs, match_lprobs, trans, entry_dist=ENTRY_DIST_OCCUPANCY, epsilon=0.01):
+        nl = np.ascontiguousarray(null_lprobs, self.np)
+        ml = np.ascontiguousarray(match_lprobs, self.np)
+        tr = np.ascontiguousarray(trans, self.np)
+        M = ml.shape[0]
+        assert ml.shape == (M, 20) and tr.shape == (M + 1, 7) and nl.shape == (20,)
+        h = self.lib.orc_profile_new(M, entry_dist, float(np.float32(epsilon)), nl.ctypes.data,
+                                     ml.ctypes.data, tr.ctypes.data)
+        assert h
+        return Profile(self, h)
+
+    def state_name(self, sid):
+        b = C.create_string_buffer(8)
+        self.lib.orc_state_name(sid, b)
+        return b.value.decode()
+
+    def rnd_doubles(self, seed, n):
+        st = (C.c_uint64 * 4)()
+        self.lib.orc_rnd_seed(st, seed)
+        return [self.lib.orc_rnd_dbl(st) for _ in range(n)]
+
+    def frame_table(self, dist129, eps):
+        d = np.ascontiguousarray(dist129, self.np)
+        out = np.zeros(NCODES, self.np)
+        self.lib.orc_frame_table(d.ctypes.data, float(eps), out.ctypes.data)
+        return out
+
+    def dp_tables(self, t8, em, ei, en, xt, seq: bytes):
+        t8 = np.ascontiguousarray(t8, self.np)
+        em = np.ascontiguousarray(em, self.np)
+        ei = np.ascontiguousarray(ei, self.np)
+        en = np.ascontiguousarray(en, self.np)
+        xt = np.ascontiguousarray(xt, self.np)
+        M = t8.shape[1]
+        nl, al = self.fl(), self.fl()
+        rc = self.lib.orc_dp_tables(M, M, t8.ctypes.data, em.ctypes.data, ei.ctypes.data,
+                                    en.ctypes.data, xt.ctypes.data, seq, len(seq),
+                                    C.byref(nl), C.byref(al))
+        return rc, nl.value, al.value
+
+    def scan(self, profiles, seqs, multi_hits=True, hmmer3_compat=False, lrt_thr=10.0,
+             nthreads=1, mode=0):
+        """thread_run restatement over all (seq, profile) pairs.
+        returns (hits, null[nseq, nprof], alt[nseq, nprof])."""
+        n = len(profiles)
+        arr = (C.c_void_p * n)(*[p.h for p in profiles])
+        off = np.zeros(len(seqs) + 1, np.uint32)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        cat = b"".join(seqs)
+        on = np.zeros((len(seqs), n), self.np)
+        oa = np.zeros((len(seqs), n), self.np)
+        hits = self.lib.orc_scan(arr, n, cat, off.ctypes.data, len(seqs), int(multi_hits),
+                                 int(hmmer3_compat), float(lrt_thr), nthreads, mode,
+                                 on.ctypes.data, oa.ctypes.data)
+        return hits, on, oa
