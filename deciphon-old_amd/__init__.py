@@ -1,0 +1,380 @@
+"""deciphon-old_amd -- MI355X-native profile-HMM scan engine (host binding).
+
+Thin ctypes layer over the C-ABI of ``include/dcp_gpu.h`` (``libdcp_hip.so``,
+built from ``csrc/`` by hipcc for gfx950).  It mirrors the reference's interface
+for the scan hot path so tests read like the reference's own:
+
+=====================================  =========================================
+reference (deciphon-old)               here
+=====================================  =========================================
+protein_profile_init + _sample         ``ProteinProfile.sample(seed, core_size, cfg)``
+protein_profile_init + _absorb(model)  ``ProteinProfile.from_params(...)``
+protein_profile_setup(prof, L, ...)    ``xtrans(L, multi_hits, hmmer3_compat)`` (EINVAL on L=0)
+profile_reader_setup/rewind/next       ``Scanner.upload_db(profiles)`` (resident, once)
+imm_seq + imm_task_setup               ``Scanner.upload_seqs(seqs)``
+thread_run (per (seq, profile) pair)   ``Scanner.scan(multi_hits, hmmer3_compat, lrt_threshold)``
+xmath_lrt                              ``lrt(null, alt)``
+=====================================  =========================================
+
+There is NO CPU fallback: importing works without a GPU (so the host logic and
+the symbol table can be tested), but creating a ``Scanner`` without a HIP device
+raises, and a missing ``libdcp_hip.so`` raises at import.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libdcp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# enum rc (include/deciphon/core/rc.h:4-15)
+RC_OK, RC_END, RC_EFAIL, RC_EINVAL, RC_EIO, RC_ENOMEM, RC_EPARSE, RC_EAPI, RC_EHTTP = range(9)
+RC_NAMES = ["RC_OK", "RC_END", "RC_EFAIL", "RC_EINVAL", "RC_EIO", "RC_ENOMEM", "RC_EPARSE",
+            "RC_EAPI", "RC_EHTTP"]
+# enum entry_dist (include/deciphon/model/entry_dist.h)
+ENTRY_DIST_NULL, ENTRY_DIST_UNIFORM, ENTRY_DIST_OCCUPANCY = 0, 1, 2
+NCODES = 1364
+NDIST = 129
+NXTRANS = 13
+CORE_SIZE_MAX = 4096
+NUM_THREADS = 64
+
+# every symbol include/dcp_gpu.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "dcp_profile_new", "dcp_profile_sample", "dcp_profile_del", "dcp_profile_core_size",
+    "dcp_profile_accession", "dcp_profile_trans8", "dcp_profile_null_dist",
+    "dcp_profile_insert_dist", "dcp_profile_match_dist", "dcp_frame_table_host", "dcp_xtrans",
+    "dcp_lrt", "dcp_partition_by_count", "dcp_partition_by_cells", "dcp_gpu_device_count",
+    "dcp_gpu_ctx_new", "dcp_gpu_ctx_del", "dcp_gpu_last_error", "dcp_gpu_stream",
+    "dcp_gpu_db_upload", "dcp_gpu_db_nprofiles", "dcp_gpu_db_fetch_match_table",
+    "dcp_gpu_seqs_upload", "dcp_gpu_seqs_upload_text", "dcp_gpu_nseqs", "dcp_gpu_scan",
+    "dcp_gpu_sync", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
+    "dcp_gpu_fetch_hits", "dcp_gpu_hits_device_ptr", "dcp_gpu_nhits_device_ptr",
+    "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
+]
+
+
+class DcpError(RuntimeError):
+    def __init__(self, rc, msg=""):
+        self.rc = rc
+        name = RC_NAMES[rc] if 0 <= rc < len(RC_NAMES) else str(rc)
+        super().__init__(f"{name}: {msg}" if msg else name)
+
+
+def build(verbose=False):
+    """Compile csrc/ for gfx950 into libdcp_hip.so (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+class ScanParams(C.Structure):
+    _fields_ = [("multi_hits", C.c_int), ("hmmer3_compat", C.c_int),
+                ("lrt_threshold", C.c_float), ("keep_scores", C.c_int)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("seq_idx", C.c_uint32), ("profile_idx", C.c_uint32),
+                ("null_loglik", C.c_float), ("alt_loglik", C.c_float)]
+
+
+HIT_DTYPE = np.dtype([("seq_idx", np.uint32), ("profile_idx", np.uint32),
+                      ("null_loglik", np.float32), ("alt_loglik", np.float32)])
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C deciphon-old_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    P, F, U, I = C.c_void_p, C.c_float, C.c_uint, C.c_int
+    sig = {
+        "dcp_profile_new": (P, [C.c_char_p, U, I, F, P, P, P, C.c_char_p, C.POINTER(I)]),
+        "dcp_profile_sample": (P, [C.c_char_p, U, U, I, F, C.POINTER(I)]),
+        "dcp_profile_del": (None, [P]),
+        "dcp_profile_core_size": (U, [P]),
+        "dcp_profile_accession": (C.c_char_p, [P]),
+        "dcp_profile_trans8": (P, [P]),
+        "dcp_profile_null_dist": (P, [P]),
+        "dcp_profile_insert_dist": (P, [P]),
+        "dcp_profile_match_dist": (P, [P]),
+        "dcp_frame_table_host": (None, [P, F, P]),
+        "dcp_xtrans": (I, [U, I, I, P]),
+        "dcp_lrt": (F, [F, F]),
+        "dcp_partition_by_count": (U, [U, U, P]),
+        "dcp_partition_by_cells": (None, [P, U, U, P]),
+        "dcp_gpu_device_count": (I, []),
+        "dcp_gpu_ctx_new": (P, [I]),
+        "dcp_gpu_ctx_del": (None, [P]),
+        "dcp_gpu_last_error": (C.c_char_p, [P]),
+        "dcp_gpu_stream": (P, [P]),
+        "dcp_gpu_db_upload": (I, [P, P, U, I]),
+        "dcp_gpu_db_nprofiles": (U, [P]),
+        "dcp_gpu_db_fetch_match_table": (I, [P, U, P]),
+        "dcp_gpu_seqs_upload": (I, [P, P, P, U]),
+        "dcp_gpu_seqs_upload_text": (I, [P, C.c_char_p, P, U]),
+        "dcp_gpu_nseqs": (U, [P]),
+        "dcp_gpu_scan": (I, [P, C.POINTER(ScanParams)]),
+        "dcp_gpu_sync": (I, [P]),
+        "dcp_gpu_last_scan_ms": (F, [P]),
+        "dcp_gpu_last_scan_launches": (U, [P]),
+        "dcp_gpu_fetch_scores": (I, [P, P, P]),
+        "dcp_gpu_fetch_hits": (I, [P, P, U, C.POINTER(U)]),
+        "dcp_gpu_hits_device_ptr": (P, [P]),
+        "dcp_gpu_nhits_device_ptr": (P, [P]),
+        "dcp_gpu_scan_cells": (C.c_uint64, [P]),
+        "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class ProteinCfg:
+    """struct protein_cfg {entry_dist, epsilon} (include/deciphon/model/protein_cfg.h)."""
+
+    def __init__(self, entry_dist=ENTRY_DIST_OCCUPANCY, epsilon=0.01):
+        if not (0.0 <= epsilon <= 1.0):  # assert in protein_cfg():18
+            raise DcpError(RC_EINVAL, "epsilon out of [0, 1]")
+        self.entry_dist = entry_dist
+        self.epsilon = float(np.float32(epsilon))
+
+
+PROTEIN_CFG_DEFAULT = ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)  # protein_cfg.h:22-23
+
+
+class ProteinProfile:
+    """The scan-time profile object (struct protein_profile, protein_profile.h:12-43) in its
+    compact device-facing form: 8 transition rows + one 129-float nuclt_dist per node."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise DcpError(RC_EINVAL, "profile construction failed")
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.dcp_profile_del(h)
+
+    @classmethod
+    def sample(cls, seed, core_size, cfg=PROTEIN_CFG_DEFAULT, accession="accession"):
+        """protein_profile_sample (src/model/protein_profile.c:259-304)."""
+        rc = C.c_int(0)
+        h = lib.dcp_profile_sample(accession.encode(), seed, core_size, cfg.entry_dist,
+                                   cfg.epsilon, C.byref(rc))
+        if not h:
+            raise DcpError(rc.value, "protein_profile_sample")
+        return cls(h)
+
+    @classmethod
+    def from_params(cls, null_lprobs, match_lprobs, trans, cfg=PROTEIN_CFG_DEFAULT,
+                    accession="accession", consensus=None):
+        """protein_model_init/setup/add_node/add_trans + protein_profile_absorb."""
+        nl, ml, tr = _f32(null_lprobs), _f32(match_lprobs), _f32(trans)
+        M = ml.shape[0] if ml.ndim == 2 else 0
+        if nl.shape != (20,) or ml.shape != (M, 20) or tr.shape != (M + 1, 7):
+            raise DcpError(RC_EINVAL, "bad parameter shapes")
+        rc = C.c_int(0)
+        cons = consensus.encode() if consensus else None
+        h = lib.dcp_profile_new(accession.encode(), M, cfg.entry_dist, cfg.epsilon,
+                                nl.ctypes.data, ml.ctypes.data, tr.ctypes.data, cons, C.byref(rc))
+        if not h:
+            raise DcpError(rc.value, "protein_model_setup")
+        return cls(h)
+
+    @property
+    def core_size(self):
+        return lib.dcp_profile_core_size(self._h)
+
+    @property
+    def accession(self):
+        return lib.dcp_profile_accession(self._h).decode()
+
+    def _view(self, ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,)).reshape(shape).copy()
+
+    @property
+    def trans8(self):
+        return self._view(lib.dcp_profile_trans8(self._h), (8, self.core_size))
+
+    @property
+    def null_dist(self):
+        return self._view(lib.dcp_profile_null_dist(self._h), (NDIST,))
+
+    @property
+    def insert_dist(self):
+        return self._view(lib.dcp_profile_insert_dist(self._h), (NDIST,))
+
+    @property
+    def match_dist(self):
+        return self._view(lib.dcp_profile_match_dist(self._h), (self.core_size, NDIST))
+
+
+def frame_table_host(dist, epsilon):
+    d = _f32(dist)
+    out = np.zeros(NCODES, np.float32)
+    lib.dcp_frame_table_host(d.ctypes.data, float(np.float32(epsilon)), out.ctypes.data)
+    return out
+
+
+def xtrans(seq_size, multi_hits=True, hmmer3_compat=False):
+    """protein_profile_setup's 13 special transitions (protein_profile.c:155-216).
+    Raises RC_EINVAL for an empty sequence, as the reference returns."""
+    out = np.zeros(NXTRANS, np.float32)
+    rc = lib.dcp_xtrans(seq_size, int(multi_hits), int(hmmer3_compat), out.ctypes.data)
+    if rc:
+        raise DcpError(rc, "sequence cannot be empty")
+    return out
+
+
+def lrt(null_loglik, alt_loglik):
+    """xmath_lrt_f32 (include/deciphon/core/xmath.h:32-35)."""
+    return lib.dcp_lrt(float(null_loglik), float(alt_loglik))
+
+
+def partition_by_count(nprofiles, npartitions):
+    """profile_reader partition sizes (src/db/profile_reader.c:54-72)."""
+    sizes = np.zeros(NUM_THREADS, np.uint32)
+    n = lib.dcp_partition_by_count(nprofiles, npartitions, sizes.ctypes.data)
+    if n == 0:
+        raise DcpError(RC_EINVAL, "can't have zero partitions / too many partitions")
+    return sizes[:n].tolist()
+
+
+def partition_by_cells(core_sizes, npartitions):
+    """Contiguous shards balanced by sum of core sizes: one per GPU."""
+    cs = np.ascontiguousarray(core_sizes, np.uint32)
+    out = np.zeros(npartitions + 1, np.uint32)
+    lib.dcp_partition_by_cells(cs.ctypes.data, len(cs), npartitions, out.ctypes.data)
+    return out.tolist()
+
+
+def encode_seq(text):
+    """ACGT text -> symbol ids (imm_dna_iupac order); anything else -> 255."""
+    lut = np.full(256, 255, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    return lut[np.frombuffer(text.encode() if isinstance(text, str) else text, np.uint8)]
+
+
+def device_count():
+    return lib.dcp_gpu_device_count()
+
+
+class Scanner:
+    """One device context = one reference "partition" (thread_run's unit, scan.c:239-249):
+    holds a profile shard resident in HBM and scans sequence batches against it."""
+
+    def __init__(self, device=0):
+        self._c = lib.dcp_gpu_ctx_new(device)
+        if not self._c:
+            raise DcpError(RC_EFAIL, f"no HIP device {device}: this engine has no CPU fallback")
+        self._profiles = None
+
+    def close(self):
+        c, self._c = getattr(self, "_c", None), None
+        if c:
+            lib.dcp_gpu_ctx_del(c)
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise DcpError(rc, lib.dcp_gpu_last_error(self._c).decode())
+
+    @property
+    def stream(self):
+        return lib.dcp_gpu_stream(self._c)
+
+    def upload_db(self, profiles, expand_on_host=False):
+        arr = (C.c_void_p * len(profiles))(*[p._h for p in profiles])
+        self._check(lib.dcp_gpu_db_upload(self._c, arr, len(profiles), int(expand_on_host)))
+        self._profiles = list(profiles)
+
+    @property
+    def nprofiles(self):
+        return lib.dcp_gpu_db_nprofiles(self._c)
+
+    @property
+    def nseqs(self):
+        return lib.dcp_gpu_nseqs(self._c)
+
+    def match_table(self, p):
+        M = self._profiles[p].core_size
+        out = np.zeros((NCODES, M), np.float32)
+        self._check(lib.dcp_gpu_db_fetch_match_table(self._c, p, out.ctypes.data))
+        return out
+
+    def upload_seqs(self, seqs):
+        """seqs: list of ACGT strings, or of uint8 arrays / bytes of symbol ids 0..3."""
+        if len(seqs) and isinstance(seqs[0], str):
+            seqs = [encode_seq(s) for s in seqs]
+        arrs = [np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else
+                np.ascontiguousarray(s, np.uint8) for s in seqs]
+        off = np.zeros(len(arrs) + 1, np.uint32)
+        if arrs:
+            off[1:] = np.cumsum([len(a) for a in arrs])
+        cat = np.ascontiguousarray(np.concatenate(arrs)) if arrs else np.zeros(0, np.uint8)
+        self.upload_seqs_flat(cat, off)
+
+    def upload_seqs_flat(self, cat, off):
+        cat = np.ascontiguousarray(cat, np.uint8)
+        off = np.ascontiguousarray(off, np.uint32)
+        self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
+
+    def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
+             sync=True):
+        prm = ScanParams(int(multi_hits), int(hmmer3_compat), float(lrt_threshold), int(keep_scores))
+        self._check(lib.dcp_gpu_scan(self._c, C.byref(prm)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(lib.dcp_gpu_sync(self._c))
+
+    @property
+    def last_scan_ms(self):
+        return lib.dcp_gpu_last_scan_ms(self._c)
+
+    @property
+    def last_scan_launches(self):
+        return lib.dcp_gpu_last_scan_launches(self._c)
+
+    @property
+    def cells(self):
+        return lib.dcp_gpu_scan_cells(self._c)
+
+    @property
+    def algorithmic_bytes(self):
+        return lib.dcp_gpu_scan_algorithmic_bytes(self._c)
+
+    def scores(self):
+        """(null[nseqs, nprofiles], alt[nseqs, nprofiles]) of the last scan."""
+        nl = np.zeros((self.nseqs, self.nprofiles), np.float32)
+        al = np.zeros_like(nl)
+        self._check(lib.dcp_gpu_fetch_scores(self._c, nl.ctypes.data, al.ctypes.data))
+        return nl, al
+
+    def hits(self, cap=1 << 20):
+        buf = np.zeros(cap, HIT_DTYPE)
+        n = C.c_uint(0)
+        rc = lib.dcp_gpu_fetch_hits(self._c, buf.ctypes.data, cap, C.byref(n))
+        if rc == RC_ENOMEM and n.value > cap:
+            return self.hits(n.value)
+        self._check(rc)
+        return buf[:n.value]

@@ -1,0 +1,618 @@
+// dcp_gpu.hip -- C-ABI of the device path (include/dcp_gpu.h): context, resident
+// profile DB, resident sequence batch, scan launch, result fetch.
+//
+// Replaces, for the hot path only: profile_reader_* + protein_profile.unpack
+// (src/db/profile_reader.c:74-168, src/model/protein_profile.c:38-117),
+// imm_task_setup (src/server/scan_thread.c:51-55) and the per-pair body of
+// thread_run (src/server/scan_thread.c:99-123).  No CPU fallback exists.
+#include "dcp_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+// Size classes: a profile with core_size M runs in the smallest class whose
+// capacity 64*R*W holds it (R nodes per lane, W wavefronts per pair).
+struct SizeClass
+{
+    int R, W;
+    unsigned cap() const { return 64u * (unsigned)R * (unsigned)W; }
+};
+constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1},  {4, 1},  {3, 2},  {4, 2},
+                                  {3, 4}, {4, 4}, {3, 8},  {4, 8},  {3, 16}, {4, 16}};
+constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
+
+int class_of(unsigned M)
+{
+    for (int c = 0; c < kNumClasses; ++c)
+        if (M <= kClasses[c].cap()) return c;
+    return -1;
+}
+
+template <class T> struct DevBuf
+{
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct dcp_gpu_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::string err;
+
+    // resident DB
+    unsigned nprof = 0;
+    std::vector<dcp_prof_meta> metas;   // sorted by class
+    std::vector<unsigned> core_sizes;   // by pidx
+    unsigned class_first[kNumClasses + 1] = {0};
+    DevBuf<dcp_prof_meta> d_metas;
+    DevBuf<float> d_emis_match, d_emis_insert, d_emis_null, d_trans8;
+
+    // resident sequences
+    unsigned nseqs = 0;
+    uint64_t total_len = 0;
+    std::vector<uint32_t> seq_len;
+    DevBuf<uint32_t> d_seq_words, d_seq_woff, d_seq_len;
+    DevBuf<float> d_xtrans;
+    int xt_multi = -1, xt_h3 = -1;
+
+    // results
+    DevBuf<float> d_null, d_alt;
+    DevBuf<dcp_hit> d_hits;
+    DevBuf<unsigned> d_nhits;
+    unsigned hit_cap = 0;
+    bool have_scores = false;
+    unsigned last_launches = 0;
+    bool scanned = false;
+
+    int fail(int rc, char const *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        fprintf(stderr, "dcp_gpu: %s\n", buf);
+        return rc;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                     \
+    do                                                                         \
+    {                                                                          \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? DCP_ENOMEM : DCP_EFAIL, \
+                               "%s: %s", #call, hipGetErrorString(e_));        \
+    } while (0)
+
+extern "C" {
+
+int dcp_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
+{
+    int n = dcp_gpu_device_count();
+    if (n <= 0 || device < 0 || device >= n)
+    {
+        fprintf(stderr,
+                "dcp_gpu: no HIP device %d (found %d); this engine has no CPU "
+                "fallback\n",
+                device, n);
+        return nullptr;
+    }
+    dcp_gpu_ctx *c = new (std::nothrow) dcp_gpu_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev_start) != hipSuccess ||
+        hipEventCreate(&c->ev_stop) != hipSuccess)
+    {
+        fprintf(stderr, "dcp_gpu: failed to create stream/events on device %d\n", device);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+char const *dcp_gpu_last_error(dcp_gpu_ctx const *c) { return c ? c->err.c_str() : "no context"; }
+void *dcp_gpu_stream(dcp_gpu_ctx *c) { return (void *)c->stream; }
+unsigned dcp_gpu_db_nprofiles(dcp_gpu_ctx const *c) { return c->nprof; }
+unsigned dcp_gpu_nseqs(dcp_gpu_ctx const *c) { return c->nseqs; }
+
+// ---------------------------------------------------------------------------
+// DB upload
+// ---------------------------------------------------------------------------
+int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
+                      unsigned nprofiles, int expand_on_host)
+{
+    if (!c) return DCP_EINVAL;
+    if (!profiles || nprofiles == 0) return c->fail(DCP_EINVAL, "empty profile list");
+    if (nprofiles > (1u << 20)) return c->fail(DCP_EINVAL, "too many profiles"); // MAX_NPROFILES limits.h:7
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->scanned = false;
+
+    // classify and order: by size class, then by caller index
+    std::vector<int> cls(nprofiles);
+    c->core_sizes.assign(nprofiles, 0);
+    for (unsigned p = 0; p < nprofiles; ++p)
+    {
+        if (!profiles[p]) return c->fail(DCP_EINVAL, "null profile %u", p);
+        unsigned M = dcp_profile_core_size(profiles[p]);
+        int k = class_of(M);
+        if (k < 0) return c->fail(DCP_EINVAL, "profile %u: core_size %u too big", p, M);
+        cls[p] = k;
+        c->core_sizes[p] = M;
+    }
+    std::vector<unsigned> order(nprofiles);
+    for (unsigned p = 0; p < nprofiles; ++p)
+        order[p] = p;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](unsigned a, unsigned b) { return cls[a] < cls[b]; });
+
+    c->metas.assign(nprofiles, dcp_prof_meta{});
+    std::vector<uint32_t> dist_row(nprofiles);
+    uint64_t emis_floats = 0, trans_floats = 0, match_rows = 0;
+    for (int k = 0; k <= kNumClasses; ++k)
+        c->class_first[k] = 0;
+    for (unsigned i = 0; i < nprofiles; ++i)
+    {
+        unsigned p = order[i];
+        unsigned ldk = kClasses[cls[p]].cap();
+        dcp_prof_meta &m = c->metas[i];
+        m.emis_off = emis_floats;
+        m.trans_off = (uint32_t)trans_floats;
+        m.core_size = c->core_sizes[p];
+        m.ldk = ldk;
+        m.pidx = p;
+        dist_row[i] = (uint32_t)match_rows;
+        emis_floats += (uint64_t)DCP_NCODES * ldk;
+        trans_floats += 8ull * ldk;
+        match_rows += m.core_size;
+        c->class_first[cls[p] + 1] = i + 1;
+    }
+    for (int k = 1; k <= kNumClasses; ++k) // empty classes inherit the boundary
+        if (c->class_first[k] < c->class_first[k - 1]) c->class_first[k] = c->class_first[k - 1];
+    if (trans_floats > 0xffffffffull || match_rows > 0xffffffffull)
+        return c->fail(DCP_EINVAL, "DB too large for 32-bit row offsets");
+
+    HIP_TRY(c, c->d_metas.alloc(nprofiles));
+    HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
+    HIP_TRY(c, c->d_trans8.alloc(trans_floats));
+    HIP_TRY(c, c->d_emis_insert.alloc((size_t)nprofiles * DCP_NCODES));
+    HIP_TRY(c, c->d_emis_null.alloc((size_t)nprofiles * DCP_NCODES));
+    HIP_TRY(c, hipMemcpyAsync(c->d_metas.p, c->metas.data(), nprofiles * sizeof(dcp_prof_meta),
+                              hipMemcpyHostToDevice, c->stream));
+
+    // transitions, padded with -inf (unreachable padding nodes)
+    {
+        float const ninf = -std::numeric_limits<float>::infinity();
+        std::vector<float> t8(trans_floats, ninf);
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_prof_meta const &m = c->metas[i];
+            float const *src = dcp_profile_trans8(profiles[m.pidx]);
+            for (int row = 0; row < 8; ++row)
+                std::memcpy(&t8[m.trans_off + (size_t)row * m.ldk], src + (size_t)row * m.core_size,
+                            sizeof(float) * m.core_size);
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_trans8.p, t8.data(), t8.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+
+    if (expand_on_host)
+    {
+        // parity path: tables from dcp_frame_table_host, profile by profile
+        std::vector<float> col(DCP_NCODES), tab;
+        std::vector<float> ins((size_t)nprofiles * DCP_NCODES), nul((size_t)nprofiles * DCP_NCODES);
+        float const ninf = -std::numeric_limits<float>::infinity();
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_prof_meta const &m = c->metas[i];
+            dcp_profile const *pr = profiles[m.pidx];
+            float eps = dcp_profile_epsilon(pr);
+            tab.assign((size_t)DCP_NCODES * m.ldk, ninf);
+            float const *md = dcp_profile_match_dist(pr);
+            for (unsigned k = 0; k < m.core_size; ++k)
+            {
+                dcp_frame_table_host(md + (size_t)k * DCP_NDIST, eps, col.data());
+                for (unsigned code = 0; code < DCP_NCODES; ++code)
+                    tab[(size_t)code * m.ldk + k] = col[code];
+            }
+            HIP_TRY(c, hipMemcpy(c->d_emis_match.p + m.emis_off, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+            dcp_frame_table_host(dcp_profile_insert_dist(pr), eps, &ins[(size_t)m.pidx * DCP_NCODES]);
+            dcp_frame_table_host(dcp_profile_null_dist(pr), eps, &nul[(size_t)m.pidx * DCP_NCODES]);
+        }
+        HIP_TRY(c, hipMemcpy(c->d_emis_insert.p, ins.data(), ins.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_emis_null.p, nul.data(), nul.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    else
+    {
+        // dists rows: all match nodes (sorted profile order), then insert dists
+        // by pidx, then null dists by pidx
+        size_t const rows = (size_t)match_rows + 2 * (size_t)nprofiles;
+        std::vector<float> dists(rows * DCP_NDIST), eps(rows);
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_prof_meta const &m = c->metas[i];
+            dcp_profile const *pr = profiles[m.pidx];
+            std::memcpy(&dists[(size_t)dist_row[i] * DCP_NDIST], dcp_profile_match_dist(pr),
+                        sizeof(float) * DCP_NDIST * m.core_size);
+            std::fill(eps.begin() + dist_row[i], eps.begin() + dist_row[i] + m.core_size,
+                      dcp_profile_epsilon(pr));
+        }
+        for (unsigned p = 0; p < nprofiles; ++p)
+        {
+            std::memcpy(&dists[((size_t)match_rows + p) * DCP_NDIST], dcp_profile_insert_dist(profiles[p]),
+                        sizeof(float) * DCP_NDIST);
+            std::memcpy(&dists[((size_t)match_rows + nprofiles + p) * DCP_NDIST],
+                        dcp_profile_null_dist(profiles[p]), sizeof(float) * DCP_NDIST);
+            eps[(size_t)match_rows + p] = eps[(size_t)match_rows + nprofiles + p] =
+                dcp_profile_epsilon(profiles[p]);
+        }
+        std::vector<dcp_expand_tile> tiles;
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_prof_meta const &m = c->metas[i];
+            for (unsigned k0 = 0; k0 < m.ldk; k0 += 64)
+            {
+                dcp_expand_tile t{};
+                t.out_off = m.emis_off + k0;
+                t.ncols = k0 < m.core_size ? std::min(64u, m.core_size - k0) : 0u;
+                t.dist_row = t.ncols ? dist_row[i] + k0 : 0u;
+                t.nstore = 64;
+                t.ld_code = m.ldk;
+                t.ld_col = 1;
+                tiles.push_back(t);
+            }
+        }
+        size_t const n_match_tiles = tiles.size();
+        for (int which = 0; which < 2; ++which)
+            for (unsigned p0 = 0; p0 < nprofiles; p0 += 64)
+            {
+                dcp_expand_tile t{};
+                t.out_off = (uint64_t)p0 * DCP_NCODES;
+                t.ncols = t.nstore = std::min(64u, nprofiles - p0);
+                t.dist_row = (uint32_t)(match_rows + (which ? nprofiles : 0) + p0);
+                t.ld_code = 1;
+                t.ld_col = DCP_NCODES;
+                tiles.push_back(t);
+            }
+        size_t const n_special_tiles = (tiles.size() - n_match_tiles) / 2;
+
+        DevBuf<float> d_dists, d_eps;
+        DevBuf<dcp_expand_tile> d_tiles;
+        HIP_TRY(c, d_dists.alloc(dists.size()));
+        HIP_TRY(c, d_eps.alloc(eps.size()));
+        HIP_TRY(c, d_tiles.alloc(tiles.size()));
+        HIP_TRY(c, hipMemcpy(d_dists.p, dists.data(), dists.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_eps.p, eps.data(), eps.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * sizeof(dcp_expand_tile), hipMemcpyHostToDevice));
+        dcp_expand_args ea{d_tiles.p, d_dists.p, d_eps.p, c->d_emis_match.p};
+        dcp_launch_expand(&ea, (unsigned)n_match_tiles, c->stream);
+        ea.tiles = d_tiles.p + n_match_tiles;
+        ea.out = c->d_emis_insert.p;
+        dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
+        ea.tiles = d_tiles.p + n_match_tiles + n_special_tiles;
+        ea.out = c->d_emis_null.p;
+        dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->nprof = nprofiles;
+    return DCP_OK;
+}
+
+int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *c, unsigned p, float *out)
+{
+    if (!c || !out || p >= c->nprof) return DCP_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (dcp_prof_meta const &m : c->metas)
+        if (m.pidx == p)
+        {
+            std::vector<float> tab((size_t)DCP_NCODES * m.ldk);
+            HIP_TRY(c, hipMemcpy(tab.data(), c->d_emis_match.p + m.emis_off, tab.size() * sizeof(float),
+                                 hipMemcpyDeviceToHost));
+            for (unsigned code = 0; code < DCP_NCODES; ++code)
+                std::memcpy(out + (size_t)code * m.core_size, &tab[(size_t)code * m.ldk],
+                            sizeof(float) * m.core_size);
+            return DCP_OK;
+        }
+    return DCP_EINVAL;
+}
+
+// ---------------------------------------------------------------------------
+// Sequences
+// ---------------------------------------------------------------------------
+static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_off,
+                       unsigned nseqs, bool text)
+{
+    if (!c) return DCP_EINVAL;
+    if (!seqs || !seq_off || nseqs == 0) return c->fail(DCP_EINVAL, "empty sequence batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->scanned = false;
+    std::vector<uint32_t> woff(nseqs), len(nseqs);
+    uint64_t nwords = 0, total = 0;
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        if (seq_off[q + 1] <= seq_off[q])
+            return c->fail(DCP_EINVAL, "sequence cannot be empty"); // protein_profile.c:158
+        uint32_t L = seq_off[q + 1] - seq_off[q];
+        woff[q] = (uint32_t)nwords;
+        len[q] = L;
+        nwords += L / 16 + 1; // +1: the look-ahead base of the last row stays in bounds
+        total += L;
+        if (nwords > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
+    }
+    std::vector<uint32_t> words(nwords, 0u);
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        uint8_t const *s = seqs + seq_off[q];
+        uint32_t *w = &words[woff[q]];
+        for (uint32_t i = 0; i < len[q]; ++i)
+        {
+            unsigned b = s[i];
+            if (text)
+            {
+                switch (s[i])
+                {
+                case 'A': b = 0; break;
+                case 'C': b = 1; break;
+                case 'G': b = 2; break;
+                case 'T': b = 3; break;
+                default: b = 255; break;
+                }
+            }
+            if (b > 3)
+                return c->fail(DCP_EINVAL, "sequence %u: symbol at %u is outside ACGT", q, i);
+            w[i >> 4] |= b << ((i & 15u) * 2u);
+        }
+    }
+    HIP_TRY(c, c->d_seq_words.alloc(nwords));
+    HIP_TRY(c, c->d_seq_woff.alloc(nseqs));
+    HIP_TRY(c, c->d_seq_len.alloc(nseqs));
+    HIP_TRY(c, c->d_xtrans.alloc((size_t)nseqs * DCP_XSTRIDE));
+    HIP_TRY(c, hipMemcpy(c->d_seq_words.p, words.data(), nwords * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_seq_woff.p, woff.data(), nseqs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_seq_len.p, len.data(), nseqs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->seq_len = len;
+    c->nseqs = nseqs;
+    c->total_len = total;
+    c->xt_multi = c->xt_h3 = -1;
+    return DCP_OK;
+}
+
+int dcp_gpu_seqs_upload(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_off, unsigned nseqs)
+{
+    return upload_seqs(c, seqs, seq_off, nseqs, false);
+}
+
+int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *c, char const *text, uint32_t const *seq_off, unsigned nseqs)
+{
+    return upload_seqs(c, (uint8_t const *)text, seq_off, nseqs, true);
+}
+
+// ---------------------------------------------------------------------------
+// Scan
+// ---------------------------------------------------------------------------
+int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
+{
+    if (!c || !prm) return DCP_EINVAL;
+    if (c->nprof == 0) return c->fail(DCP_EINVAL, "no profile DB resident");
+    if (c->nseqs == 0) return c->fail(DCP_EINVAL, "no sequences resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    // protein_profile_setup once per sequence instead of once per pair
+    if (c->xt_multi != !!prm->multi_hits || c->xt_h3 != !!prm->hmmer3_compat)
+    {
+        std::vector<float> xt((size_t)c->nseqs * DCP_XSTRIDE, 0.0f);
+        std::map<uint32_t, std::vector<float>> by_len;
+        for (unsigned q = 0; q < c->nseqs; ++q)
+        {
+            auto it = by_len.find(c->seq_len[q]);
+            if (it == by_len.end())
+            {
+                std::vector<float> v(DCP_XSTRIDE, 0.0f);
+                int rc = dcp_xtrans(c->seq_len[q], prm->multi_hits, prm->hmmer3_compat, v.data());
+                if (rc) return c->fail(rc, "sequence cannot be empty");
+                it = by_len.emplace(c->seq_len[q], std::move(v)).first;
+            }
+            std::memcpy(&xt[(size_t)q * DCP_XSTRIDE], it->second.data(), sizeof(float) * DCP_XSTRIDE);
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_xtrans.p, xt.data(), xt.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->xt_multi = !!prm->multi_hits;
+        c->xt_h3 = !!prm->hmmer3_compat;
+    }
+
+    size_t const npairs = (size_t)c->nseqs * c->nprof;
+    if (prm->keep_scores)
+    {
+        if (c->d_null.n != npairs)
+        {
+            HIP_TRY(c, c->d_null.alloc(npairs));
+            HIP_TRY(c, c->d_alt.alloc(npairs));
+        }
+    }
+    c->have_scores = prm->keep_scores != 0;
+    unsigned want_cap = (unsigned)std::min<size_t>(npairs, (size_t)1 << 22);
+    if (c->hit_cap < want_cap)
+    {
+        HIP_TRY(c, c->d_hits.alloc(want_cap));
+        c->hit_cap = want_cap;
+    }
+    if (!c->d_nhits.p) HIP_TRY(c, c->d_nhits.alloc(1));
+
+    dcp_scan_args a{};
+    a.profs = c->d_metas.p;
+    a.emis_match = c->d_emis_match.p;
+    a.emis_insert = c->d_emis_insert.p;
+    a.emis_null = c->d_emis_null.p;
+    a.trans8 = c->d_trans8.p;
+    a.seq_words = c->d_seq_words.p;
+    a.seq_woff = c->d_seq_woff.p;
+    a.seq_len = c->d_seq_len.p;
+    a.xtrans = c->d_xtrans.p;
+    a.out_null = c->have_scores ? c->d_null.p : nullptr;
+    a.out_alt = c->have_scores ? c->d_alt.p : nullptr;
+    a.hits = c->d_hits.p;
+    a.nhits = c->d_nhits.p;
+    a.hit_cap = c->hit_cap;
+    a.lrt_threshold = prm->lrt_threshold;
+    a.nprof_total = c->nprof;
+    a.nseqs = c->nseqs;
+    a.qchunk = c->nseqs >= 4096 ? 32u : (c->nseqs >= 256 ? 8u : 1u);
+    a.nchunks = (c->nseqs + a.qchunk - 1) / a.qchunk;
+
+    HIP_TRY(c, hipMemsetAsync(c->d_nhits.p, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    c->last_launches = 0;
+    for (int k = 0; k < kNumClasses; ++k)
+    {
+        unsigned first = c->class_first[k], last = c->class_first[k + 1];
+        if (last <= first) continue;
+        a.first_prof = first;
+        a.nprof = last - first;
+        SizeClass const sc = kClasses[k];
+        if (sc.W != 1)
+            return c->fail(DCP_EINVAL, "core_size > 256 not supported by this build");
+        uint64_t ntasks = (uint64_t)a.nprof * a.nchunks;
+        uint64_t nblocks = (ntasks + 3) / 4;
+        nblocks = (nblocks + 7) / 8 * 8;
+        if (nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
+        if (dcp_launch_rowsweep(sc.R, &a, (unsigned)nblocks, c->stream))
+            return c->fail(DCP_EFAIL, "no kernel for class R=%d", sc.R);
+        c->last_launches++;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->scanned = true;
+    return DCP_OK;
+}
+
+int dcp_gpu_sync(dcp_gpu_ctx *c)
+{
+    if (!c) return DCP_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCP_OK;
+}
+
+float dcp_gpu_last_scan_ms(dcp_gpu_ctx *c)
+{
+    if (!c || !c->scanned) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *c) { return c ? c->last_launches : 0; }
+
+int dcp_gpu_fetch_scores(dcp_gpu_ctx *c, float *null_out, float *alt_out)
+{
+    if (!c) return DCP_EINVAL;
+    if (!c->scanned || !c->have_scores) return c->fail(DCP_EINVAL, "no dense scores kept by the last scan");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    size_t const bytes = (size_t)c->nseqs * c->nprof * sizeof(float);
+    if (null_out) HIP_TRY(c, hipMemcpy(null_out, c->d_null.p, bytes, hipMemcpyDeviceToHost));
+    if (alt_out) HIP_TRY(c, hipMemcpy(alt_out, c->d_alt.p, bytes, hipMemcpyDeviceToHost));
+    return DCP_OK;
+}
+
+int dcp_gpu_fetch_hits(dcp_gpu_ctx *c, struct dcp_hit *hits, unsigned cap, unsigned *nhits)
+{
+    if (!c || !nhits) return DCP_EINVAL;
+    if (!c->scanned) return c->fail(DCP_EINVAL, "no scan to fetch hits from");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->d_nhits.p, sizeof n, hipMemcpyDeviceToHost));
+    *nhits = n;
+    if (n > c->hit_cap) return c->fail(DCP_ENOMEM, "device hit buffer overflow: %u > %u", n, c->hit_cap);
+    if (n > cap || (n && !hits)) return DCP_ENOMEM;
+    if (n == 0) return DCP_OK;
+    HIP_TRY(c, hipMemcpy(hits, c->d_hits.p, (size_t)n * sizeof(dcp_hit), hipMemcpyDeviceToHost));
+    std::sort(hits, hits + n, [](dcp_hit const &x, dcp_hit const &y) {
+        return x.seq_idx != y.seq_idx ? x.seq_idx < y.seq_idx : x.profile_idx < y.profile_idx;
+    });
+    return DCP_OK;
+}
+
+void *dcp_gpu_hits_device_ptr(dcp_gpu_ctx *c) { return c ? (void *)c->d_hits.p : nullptr; }
+void *dcp_gpu_nhits_device_ptr(dcp_gpu_ctx *c) { return c ? (void *)c->d_nhits.p : nullptr; }
+
+uint64_t dcp_gpu_scan_cells(dcp_gpu_ctx const *c)
+{
+    if (!c) return 0;
+    uint64_t sumM = 0;
+    for (unsigned m : c->core_sizes)
+        sumM += m;
+    return sumM * c->total_len;
+}
+
+uint64_t dcp_gpu_scan_algorithmic_bytes(dcp_gpu_ctx const *c)
+{
+    // per pair 20*M*L + 32*(M+1) + L + 8
+    if (!c) return 0;
+    uint64_t sumM = 0, P = c->core_sizes.size(), Q = c->nseqs;
+    for (unsigned m : c->core_sizes)
+        sumM += m;
+    return 20ull * sumM * c->total_len + 32ull * (sumM + P) * Q + c->total_len * P + 8ull * P * Q;
+}
+
+} // extern "C"

@@ -1,0 +1,72 @@
+// dcp_kernels.h -- POD argument blocks shared by the kernels and their launchers.
+#ifndef DCP_KERNELS_H
+#define DCP_KERNELS_H
+
+#include "dcp_host.h"
+#include <stdint.h>
+
+// One resident profile (device array, sorted by size class then by index).
+struct dcp_prof_meta
+{
+    uint64_t emis_off;  // float offset of this profile's match table in emis_match
+    uint32_t trans_off; // float offset of its trans8[8][ldk] block
+    uint32_t core_size; // M
+    uint32_t ldk;       // padded node count = lanes * R of its size class
+    uint32_t pidx;      // index in the caller's profile order
+};
+
+struct dcp_scan_args
+{
+    dcp_prof_meta const *profs;
+    float const *emis_match;  // per profile [1364][ldk], -inf in padding columns
+    float const *emis_insert; // [nprof_total][1364]
+    float const *emis_null;   // [nprof_total][1364]
+    float const *trans8;      // per profile [8][ldk], -inf in padding columns
+    uint32_t const *seq_words; // 2-bit packed bases, 16 per word, per-seq aligned
+    uint32_t const *seq_woff;  // [nseqs] first word of each sequence
+    uint32_t const *seq_len;   // [nseqs]
+    float const *xtrans;       // [nseqs][DCP_XSTRIDE]
+    float *out_null;           // [nseqs][nprof_total] or NULL
+    float *out_alt;            // [nseqs][nprof_total] or NULL
+    dcp_hit *hits;
+    unsigned *nhits;
+    unsigned hit_cap;
+    float lrt_threshold;
+    unsigned first_prof; // first entry of profs[] in this launch's size class
+    unsigned nprof;      // profiles in this launch
+    unsigned nprof_total;
+    unsigned nseqs;
+    unsigned qchunk;  // queries per task
+    unsigned nchunks; // ceil(nseqs / qchunk)
+};
+
+// One 64-column tile of the expansion kernel.
+struct dcp_expand_tile
+{
+    uint64_t out_off;  // float offset of column 0 of this tile in `out`
+    uint32_t dist_row; // first row of dists[][129] (one row per column)
+    uint32_t ncols;    // columns backed by a dist row
+    uint32_t nstore;   // columns to write (>= ncols: the rest is -inf padding)
+    uint32_t ld_code;  // stride between consecutive codes
+    uint32_t ld_col;   // stride between consecutive columns
+};
+
+struct dcp_expand_args
+{
+    dcp_expand_tile const *tiles;
+    float const *dists; // [rows][129]
+    float const *eps;   // [rows] frame epsilon of each row
+    float *out;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
+int dcp_launch_rowsweep(int R, dcp_scan_args const *a, unsigned nblocks,
+                        void *stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,486 @@
+// dcp_kernels.hip -- gfx950 kernels of the profile-HMM scan engine.
+//
+//  expand_tables_kernel   frame-state emission tables (imm frame state,
+//                         SURVEY Appendix A) for every node of every profile,
+//                         written code-major / node-contiguous.
+//  viterbi_rowsweep_kernel<R>  exact null + alt Viterbi of one (profile, query)
+//                         pair per wavefront: the recursion of SURVEY
+//                         Appendix B = what imm_dp_viterbi computes for
+//                         thread_run (src/server/scan_thread.c:99-123).
+//
+// Arithmetic contract (bit-exact with the CPU oracle's float32 build): every
+// candidate is formed as (predecessor + transition) + emission in IEEE float32,
+// combined with max only; no multiplies, no FMA, no reassociation.
+#include "dcp_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace
+{
+
+__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
+
+// ---- cross-lane helpers (wave64 DPP) ---------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old_value, float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_value),
+                                           __builtin_bit_cast(int, v), CTRL,
+                                           ROW_MASK, BANK_MASK, false));
+}
+
+// value of lane-1 (lane 0 receives `first`)
+__device__ __forceinline__ float lane_shr1(float v, float first)
+{
+    return dpp_mov<0x138 /*wave_shr:1*/, 0xf, 0xf>(first, v);
+}
+
+// max over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ float wave_max(float v)
+{
+    float const ni = neg_inf();
+    float r = fmaxf(v, dpp_mov<0x111, 0xf, 0xf>(ni, v)); // row_shr:1
+    r = fmaxf(r, dpp_mov<0x112, 0xf, 0xf>(ni, v));       // row_shr:2
+    r = fmaxf(r, dpp_mov<0x113, 0xf, 0xf>(ni, v));       // row_shr:3
+    r = fmaxf(r, dpp_mov<0x114, 0xf, 0xe>(ni, r));       // row_shr:4
+    r = fmaxf(r, dpp_mov<0x118, 0xf, 0xc>(ni, r));       // row_shr:8
+    r = fmaxf(r, dpp_mov<0x142, 0xa, 0xf>(ni, r));       // row_bcast:15
+    r = fmaxf(r, dpp_mov<0x143, 0xc, 0xf>(ni, r));       // row_bcast:31
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
+}
+
+__device__ __forceinline__ float max5(float a, float b, float c, float d, float e)
+{
+    return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), e);
+}
+
+// ---- vector loads of R consecutive floats ----------------------------------
+template <int R> struct VecLoad;
+template <> struct VecLoad<1>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[1]) { o[0] = *p; }
+};
+template <> struct VecLoad<2>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[2])
+    {
+        float2 v = *reinterpret_cast<float2 const *>(p);
+        o[0] = v.x, o[1] = v.y;
+    }
+};
+template <> struct VecLoad<3>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[3])
+    {
+        // 12-byte rows: dwordx3 needs only dword alignment
+        struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+        f3 v = *reinterpret_cast<f3 const *>(p);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z;
+    }
+};
+template <> struct VecLoad<4>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[4])
+    {
+        float4 v = *reinterpret_cast<float4 const *>(p);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    }
+};
+
+__device__ __forceinline__ unsigned code_of(unsigned w, int l)
+{
+    // offsets 0,4,20,84,340 for lengths 1..5; last base = least significant
+    constexpr unsigned off[5] = {0u, 4u, 20u, 84u, 340u};
+    return off[l - 1] + (w & ((1u << (2 * l)) - 1u));
+}
+
+// ---- per-pair DP state held in registers -----------------------------------
+template <int R> struct PairState
+{
+    float P[5][R]; // P_k(j') = best predecessor of M_k leaving row j', slot j' % 5
+    float Q[5][R]; // Q_k(j') = best predecessor of I_k
+    float PN[5], PJ[5], PC[5], PR[5]; // same for N, J, C (alt) and R (null)
+};
+
+template <int R> struct Trans
+{
+    float ent[R], mm[R], im[R], dm[R], md[R], dd[R], mi[R], ii[R];
+};
+
+struct RowOut
+{
+    float E, C, Rn;
+};
+
+// One DP row. PH = j % 5 is compile-time so the history ring needs no moves.
+template <int R, int PH>
+__device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
+                                         float const (&em)[5][R],
+                                         float const (&eN)[5],
+                                         float const (&eI)[5],
+                                         float const *__restrict__ xt)
+{
+    constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5,
+                  s4 = (PH + 1) % 5, s5 = PH;
+    float const ni = neg_inf();
+
+    // emitting states: value = max_l ( predecessor(j-l) + emission(x[j-l..j)) )
+    float m[R], ins[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+        m[r] = max5(s.P[s1][r] + em[0][r], s.P[s2][r] + em[1][r],
+                    s.P[s3][r] + em[2][r], s.P[s4][r] + em[3][r],
+                    s.P[s5][r] + em[4][r]);
+        ins[r] = max5(s.Q[s1][r] + eI[0], s.Q[s2][r] + eI[1], s.Q[s3][r] + eI[2],
+                      s.Q[s4][r] + eI[3], s.Q[s5][r] + eI[4]);
+    }
+    float const N = max5(s.PN[s1] + eN[0], s.PN[s2] + eN[1], s.PN[s3] + eN[2],
+                         s.PN[s4] + eN[3], s.PN[s5] + eN[4]);
+    float const J = max5(s.PJ[s1] + eN[0], s.PJ[s2] + eN[1], s.PJ[s3] + eN[2],
+                         s.PJ[s4] + eN[3], s.PJ[s5] + eN[4]);
+    float const C = max5(s.PC[s1] + eN[0], s.PC[s2] + eN[1], s.PC[s3] + eN[2],
+                         s.PC[s4] + eN[3], s.PC[s5] + eN[4]);
+    float const Rn = max5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
+                          s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
+
+    // neighbours: node k-1 lives in the previous register, or the previous lane
+    float const m_left = lane_shr1(m[R - 1], ni);
+    float const i_left = lane_shr1(ins[R - 1], ni);
+
+    // delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
+    // a lane; across lanes iterate to the fixed point (exact, no reassociation)
+    float a[R], d[R];
+    a[0] = m_left + t.md[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        a[r] = m[r - 1] + t.md[r];
+    d[0] = a[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+    float d_left;
+    for (;;)
+    {
+        d_left = lane_shr1(d[R - 1], ni);
+        float const before = d[R - 1];
+        d[0] = fmaxf(a[0], d_left + t.dd[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+        if (!__any(d[R - 1] != before)) break;
+    }
+
+    // E = max over nodes of M_k and D_k (exit scores are 0: protein_model.c:441-458)
+    float e_lane = fmaxf(m[0], d[0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        e_lane = fmaxf(e_lane, fmaxf(m[r], d[r]));
+    float const E = wave_max(e_lane);
+
+    // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf)
+    float const B = fmaxf(fmaxf(N + xt[DCP_X_NB], E + xt[DCP_X_EB]), J + xt[DCP_X_JB]);
+
+    // predecessors leaving this row (overwrite the slot of row j-5)
+    {
+        float pm = m_left, pi = i_left, pd = d_left;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            float v = fmaxf(fmaxf(B + t.ent[r], pm + t.mm[r]),
+                            fmaxf(pi + t.im[r], pd + t.dm[r]));
+            s.P[PH][r] = v;
+            s.Q[PH][r] = fmaxf(m[r] + t.mi[r], ins[r] + t.ii[r]);
+            pm = m[r], pi = ins[r], pd = d[r];
+        }
+    }
+    s.PN[PH] = N + xt[DCP_X_NN];
+    s.PJ[PH] = fmaxf(E + xt[DCP_X_EJ], J + xt[DCP_X_JJ]);
+    s.PC[PH] = fmaxf(E + xt[DCP_X_EC], C + xt[DCP_X_CC]);
+    s.PR[PH] = Rn + xt[DCP_X_RR];
+    return RowOut{E, C, Rn};
+}
+
+__device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words,
+                                            unsigned pos)
+{
+    return (words[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
+}
+
+template <int R>
+__device__ __forceinline__ void load_row(float const *__restrict__ em_base,
+                                         unsigned ldk, unsigned lane_off,
+                                         float const *__restrict__ eN_tab,
+                                         float const *__restrict__ eI_tab,
+                                         unsigned w, float (&em)[5][R],
+                                         float (&eN)[5], float (&eI)[5])
+{
+#pragma unroll
+    for (int l = 1; l <= 5; ++l)
+    {
+        unsigned const c = code_of(w, l);
+        VecLoad<R>::ld(em_base + (size_t)c * ldk + lane_off, em[l - 1]);
+        eN[l - 1] = eN_tab[c];
+        eI[l - 1] = eI_tab[c];
+    }
+}
+
+} // namespace
+
+// ============================================================================
+// Exact row-sweep Viterbi, one wavefront per (profile, query) pair.
+// Lane t owns nodes [t*R, t*R+R) of the profile (core_size <= 64*R).
+// Block = 4 independent wavefronts working on consecutive query chunks of the
+// same profile (so their emission-table reads share one XCD's L2).
+// ============================================================================
+template <int R>
+__global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
+{
+    unsigned const lane = threadIdx.x & 63u;
+    unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware task map: blocks with equal (blockIdx % 8) share an XCD/L2, so
+    // give each XCD one contiguous range of tasks (= consecutive chunks of the
+    // same few profiles).  Placement only affects speed, never results.
+    unsigned const nblk = gridDim.x; // multiple of 8
+    unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    unsigned const task = vblk * 4u + wave;
+    unsigned const nchunks = a.nchunks;
+    unsigned const slot = task / nchunks;
+    if (slot >= a.nprof) return;
+    unsigned const chunk = task - slot * nchunks;
+
+    dcp_prof_meta const pm = a.profs[a.first_prof + slot];
+    float const *__restrict__ em_base = a.emis_match + pm.emis_off;
+    float const *__restrict__ eN_tab = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
+    float const *__restrict__ eI_tab = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
+    unsigned const ldk = pm.ldk;
+    unsigned const lane_off = lane * R;
+
+    Trans<R> t;
+    {
+        float const *__restrict__ tb = a.trans8 + pm.trans_off + lane_off;
+        VecLoad<R>::ld(tb + (size_t)DCP_T_ENTRY * ldk, t.ent);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MM * ldk, t.mm);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_IM * ldk, t.im);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_DM * ldk, t.dm);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MD * ldk, t.md);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_DD * ldk, t.dd);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MI * ldk, t.mi);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
+    }
+
+    unsigned const q0 = chunk * a.qchunk;
+    unsigned const q1 = min(q0 + a.qchunk, a.nseqs);
+    for (unsigned q = q0; q < q1; ++q)
+    {
+        unsigned const L = a.seq_len[q];
+        uint32_t const *__restrict__ words = a.seq_words + a.seq_woff[q];
+        float const *__restrict__ xt = a.xtrans + (size_t)q * DCP_XSTRIDE;
+        float const ni = neg_inf();
+
+        // row 0: S = 0, B = S + SB, everything else -inf
+        PairState<R> s;
+#pragma unroll
+        for (int h = 0; h < 5; ++h)
+        {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                s.P[h][r] = ni, s.Q[h][r] = ni;
+            s.PN[h] = ni, s.PJ[h] = ni, s.PC[h] = ni, s.PR[h] = ni;
+        }
+        {
+            float const B0 = 0.0f + xt[DCP_X_SB];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                s.P[0][r] = B0 + t.ent[r];
+            s.PN[0] = 0.0f + xt[DCP_X_SN];
+            s.PR[0] = 0.0f; // start lprob of R (protein_model.c:224)
+        }
+
+        float em[5][R], eN[5], eI[5];
+        float emn[5][R], eNn[5], eIn[5];
+        unsigned w = base_at(words, 0);
+        load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, em, eN, eI);
+        RowOut o{ni, ni, ni};
+        unsigned j = 1;
+
+// compute row j with the tables already in registers while the loads of row
+// j+1 are in flight (the word one past the last base is padding: harmless)
+#define DCP_ROW(PH)                                                            \
+    {                                                                          \
+        w = ((w << 2) | base_at(words, j)) & 1023u;                            \
+        load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, emn, eNn, eIn); \
+        o = dp_row<R, PH>(s, t, em, eN, eI, xt);                               \
+        _Pragma("unroll") for (int l = 0; l < 5; ++l)                          \
+        {                                                                      \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) em[l][r] = emn[l][r]; \
+            eN[l] = eNn[l], eI[l] = eIn[l];                                    \
+        }                                                                      \
+        ++j;                                                                   \
+    }
+        while (j + 4 <= L)
+        {
+            DCP_ROW(1) DCP_ROW(2) DCP_ROW(3) DCP_ROW(4) DCP_ROW(0)
+        }
+        if (j <= L) DCP_ROW(1)
+        if (j <= L) DCP_ROW(2)
+        if (j <= L) DCP_ROW(3)
+        if (j <= L) DCP_ROW(4)
+#undef DCP_ROW
+
+        float const alt = fmaxf(o.E + xt[DCP_X_ET], o.C + xt[DCP_X_CT]);
+        float const nul = o.Rn;
+        if (lane == 0)
+        {
+            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
+            if (a.out_null) a.out_null[oi] = nul;
+            if (a.out_alt) a.out_alt[oi] = alt;
+            // xmath_lrt_f32 + filter of scan_thread.c:121-123
+            float const lrt = -2 * (nul - alt);
+            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+            {
+                unsigned const h = atomicAdd(a.nhits, 1u);
+                if (h < a.hit_cap)
+                    a.hits[h] = dcp_hit{q, pm.pidx, nul, alt};
+            }
+        }
+    }
+}
+
+template __global__ void viterbi_rowsweep_kernel<1>(dcp_scan_args);
+template __global__ void viterbi_rowsweep_kernel<2>(dcp_scan_args);
+template __global__ void viterbi_rowsweep_kernel<3>(dcp_scan_args);
+template __global__ void viterbi_rowsweep_kernel<4>(dcp_scan_args);
+
+// ============================================================================
+// Emission-table expansion: out[code][k] for a tile of 64 nodes per block.
+// Same probability-domain formula as dcp_frame_table_host (dcp_model.cpp).
+// ============================================================================
+namespace
+{
+__device__ __forceinline__ double c3(double const *C, int x, int y, int z)
+{
+    return C[x * 25 + y * 5 + z];
+}
+__device__ __forceinline__ double s1(double const *C, int x)
+{
+    return c3(C, x, 4, 4) + c3(C, 4, x, 4) + c3(C, 4, 4, x);
+}
+__device__ __forceinline__ double s2(double const *C, int x, int y)
+{
+    return c3(C, 4, x, y) + c3(C, x, 4, y) + c3(C, x, y, 4);
+}
+
+__device__ double frame_prob(double const *b, double const *C, double e, double f,
+                             unsigned code)
+{
+    double const e2 = e * e, f2 = f * f;
+    if (code < 4) return e2 * f2 / 3.0 * s1(C, (int)code);
+    if (code < 20)
+    {
+        int v = (int)code - 4, x1 = v >> 2, x2 = v & 3;
+        return 2.0 * e * f2 * f / 3.0 * s2(C, x1, x2) +
+               e2 * e * f / 3.0 * (b[x2] * s1(C, x1) + b[x1] * s1(C, x2));
+    }
+    if (code < 84)
+    {
+        int v = (int)code - 20, x1 = v >> 4, x2 = (v >> 2) & 3, x3 = v & 3;
+        return f2 * f2 * c3(C, x1, x2, x3) +
+               4.0 * e2 * f2 / 9.0 *
+                   (b[x1] * s2(C, x2, x3) + b[x2] * s2(C, x1, x3) +
+                    b[x3] * s2(C, x1, x2)) +
+               e2 * e2 / 9.0 *
+                   (b[x1] * b[x2] * s1(C, x3) + b[x1] * b[x3] * s1(C, x2) +
+                    b[x2] * b[x3] * s1(C, x1));
+    }
+    if (code < 340)
+    {
+        int v = (int)code - 84;
+        int x[4] = {v >> 6, (v >> 4) & 3, (v >> 2) & 3, v & 3};
+        double one = b[x[0]] * c3(C, x[1], x[2], x[3]) + b[x[1]] * c3(C, x[0], x[2], x[3]) +
+                     b[x[2]] * c3(C, x[0], x[1], x[3]) + b[x[3]] * c3(C, x[0], x[1], x[2]);
+        double two = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j)
+            {
+                int r[2], n = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                two += b[x[i]] * b[x[j]] * s2(C, r[0], r[1]);
+            }
+        return e * f2 * f / 2.0 * one + e2 * e * f / 9.0 * two;
+    }
+    {
+        int v = (int)code - 340;
+        int x[5] = {v >> 8, (v >> 6) & 3, (v >> 4) & 3, (v >> 2) & 3, v & 3};
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 5; ++j)
+            {
+                int r[3], n = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                s += b[x[i]] * b[x[j]] * c3(C, r[0], r[1], r[2]);
+            }
+        return e2 * f2 / 10.0 * s;
+    }
+}
+} // namespace
+
+// grid.x = number of 64-node tiles over all tables; tiles[] says where each
+// one reads its dists and writes its columns.
+__global__ __launch_bounds__(256) void expand_tables_kernel(dcp_expand_args a)
+{
+    __shared__ double lin[64][DCP_NDIST + 1]; // +1: odd stride in 8-byte words
+    dcp_expand_tile const tile = a.tiles[blockIdx.x];
+    float const *__restrict__ dist = a.dists + (size_t)tile.dist_row * DCP_NDIST;
+    unsigned const nk = tile.ncols; // 0..64 columns backed by a dist row
+    for (unsigned i = threadIdx.x; i < 64u * DCP_NDIST; i += 256u)
+    {
+        unsigned k = i / DCP_NDIST, c = i - k * DCP_NDIST;
+        lin[k][c] = k < nk ? exp((double)dist[(size_t)k * DCP_NDIST + c]) : 0.0;
+    }
+    __syncthreads();
+    unsigned const k = threadIdx.x & 63u;
+    double const e = k < nk ? (double)a.eps[tile.dist_row + k] : 0.0, f = 1.0 - e;
+    float *__restrict__ out = a.out + tile.out_off + (size_t)k * tile.ld_col;
+    for (unsigned code = threadIdx.x >> 6; code < DCP_NCODES; code += 4u)
+    {
+        float v = -__builtin_inff(); // padding columns: unreachable nodes
+        if (k < nk) v = (float)log(frame_prob(&lin[k][0], &lin[k][4], e, f, code));
+        if (k < tile.nstore) out[(size_t)code * tile.ld_code] = v;
+    }
+}
+
+// ---- launchers ------------------------------------------------------------
+extern "C" void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles,
+                                  void *stream)
+{
+    hipLaunchKernelGGL(expand_tables_kernel, dim3(ntiles), dim3(256), 0,
+                       (hipStream_t)stream, *a);
+}
+
+extern "C" int dcp_launch_rowsweep(int R, dcp_scan_args const *a, unsigned nblocks,
+                                   void *stream)
+{
+    dim3 g(nblocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (R)
+    {
+    case 1: hipLaunchKernelGGL(viterbi_rowsweep_kernel<1>, g, b, 0, s, *a); break;
+    case 2: hipLaunchKernelGGL(viterbi_rowsweep_kernel<2>, g, b, 0, s, *a); break;
+    case 3: hipLaunchKernelGGL(viterbi_rowsweep_kernel<3>, g, b, 0, s, *a); break;
+    case 4: hipLaunchKernelGGL(viterbi_rowsweep_kernel<4>, g, b, 0, s, *a); break;
+    default: return -1;
+    }
+    return 0;
+}

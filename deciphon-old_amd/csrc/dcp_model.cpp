@@ -1,0 +1,463 @@
+// dcp_model.cpp -- host side of the scan engine: builds the compact profile
+// ("dcpx") the device consumes. Product code; never calls the oracle.
+//
+// Restates, MI355X-first, what the reference's model layer computes:
+//   protein_model_init / add_node / add_trans / setup_transitions
+//       src/model/protein_model.c:49-137, 460-500
+//   setup_nuclt_dist / codon_lprob / nuclt_lprob      :342-408
+//   calculate_occupancy, setup_entry_trans            :258-283, :410-439
+//   protein_profile_sample / setup                    src/model/protein_profile.c:155-304
+// Differences by design: the reference keeps per-state imm_dp emission tables
+// on the host and re-reads them per pair; here only the 129-float nuclt_dist
+// per node and an 8-row transition matrix are kept, and all arithmetic is done
+// in double in the probability domain and rounded once to float32 (imm_float).
+#include "dcp_host.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace
+{
+constexpr double kNegInf = -std::numeric_limits<double>::infinity();
+constexpr float kNegInfF = -std::numeric_limits<float>::infinity();
+
+// --- imm_rnd: xoshiro256+ seeded with splitmix64 (pinned by the reference's
+// golden test/protein_profile.c:41 through the oracle's search) -------------
+struct Rnd
+{
+    uint64_t s[4];
+    explicit Rnd(uint64_t seed)
+    {
+        for (auto &v : s)
+        {
+            uint64_t z = (seed += 0x9e3779b97f4a7c15ULL);
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+            v = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    double next()
+    {
+        uint64_t const r = s[0] + s[3];
+        uint64_t const t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return (double)(r >> 11) * 0x1.0p-53;
+    }
+};
+
+double logsumexp(double const *v, int n)
+{
+    double m = kNegInf;
+    for (int i = 0; i < n; ++i)
+        m = std::fmax(m, v[i]);
+    if (!(m > kNegInf)) return kNegInf;
+    double s = 0;
+    for (int i = 0; i < n; ++i)
+        s += std::exp(v[i] - m);
+    return m + std::log(s);
+}
+
+double logadd(double a, double b)
+{
+    double v[2] = {a, b};
+    return logsumexp(v, 2);
+}
+
+// imm_lprob_sample + imm_lprob_normalize on imm_float values
+void sample_normalized(Rnd &rnd, int n, float *out, int const *force_zero,
+                       int nforce)
+{
+    std::vector<double> lp((size_t)n);
+    for (int i = 0; i < n; ++i)
+        lp[(size_t)i] = (double)(float)std::log(rnd.next());
+    for (int i = 0; i < nforce; ++i)
+        lp[(size_t)force_zero[i]] = kNegInf;
+    double z = logsumexp(lp.data(), n);
+    for (int i = 0; i < n; ++i)
+        out[i] = (float)(lp[(size_t)i] - z);
+}
+
+// NCBI genetic code 1 (imm_gc table 1), codon index = 16*b1 + 4*b2 + b3 in the
+// TCAG order of the published table; converted to ACGT ids below.
+constexpr char kGcAmino[] =
+    "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+constexpr int kTcagToAcgt[4] = {3, 1, 0, 2};
+constexpr char kAminoSymbols[] = "ACDEFGHIKLMNPQRSTVWY";
+
+struct CodonTable
+{
+    char aa[64];        // amino acid (or '*') of codon a*16+b*4+c in ACGT ids
+    int synonyms[128];  // number of codons per amino acid letter
+    CodonTable()
+    {
+        std::memset(synonyms, 0, sizeof synonyms);
+        for (int i = 0; i < 64; ++i)
+        {
+            int a = kTcagToAcgt[i >> 4], b = kTcagToAcgt[(i >> 2) & 3],
+                c = kTcagToAcgt[i & 3];
+            aa[a * 16 + b * 4 + c] = kGcAmino[i];
+            synonyms[(int)kGcAmino[i]]++;
+        }
+    }
+};
+CodonTable const g_codons;
+
+// setup_nuclt_dist: amino log-(odds|probs) -> 4 base lprobs + 125 codon marginals
+void make_nuclt_dist(float const aa_lprobs[20], float out[DCP_NDIST])
+{
+    double by_letter[128];
+    for (double &v : by_letter)
+        v = kNegInf;
+    for (int i = 0; i < 20; ++i)
+    {
+        int letter = kAminoSymbols[i];
+        by_letter[letter] =
+            (double)aa_lprobs[i] - std::log((double)g_codons.synonyms[letter]);
+    }
+    double codon_lp[64];
+    for (int i = 0; i < 64; ++i)
+        codon_lp[i] = by_letter[(int)g_codons.aa[i]]; // stops ('*') stay -inf
+    double z = logsumexp(codon_lp, 64);
+    double p[64]; // probability domain from here on
+    for (int i = 0; i < 64; ++i)
+        p[i] = std::exp(codon_lp[i] - z);
+
+    double base[4] = {0, 0, 0, 0};
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            for (int c = 0; c < 4; ++c)
+            {
+                double third = p[a * 16 + b * 4 + c] / 3.0;
+                base[a] += third;
+                base[b] += third;
+                base[c] += third;
+            }
+    for (int i = 0; i < 4; ++i)
+        out[i] = (float)std::log(base[i]);
+
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            for (int c = 0; c < 5; ++c)
+            {
+                double s = 0;
+                for (int i = (a == 4 ? 0 : a); i < (a == 4 ? 4 : a + 1); ++i)
+                    for (int j = (b == 4 ? 0 : b); j < (b == 4 ? 4 : b + 1); ++j)
+                        for (int k = (c == 4 ? 0 : c); k < (c == 4 ? 4 : c + 1); ++k)
+                            s += p[i * 16 + j * 4 + k];
+                out[4 + a * 25 + b * 5 + c] = (float)std::log(s);
+            }
+}
+
+} // namespace
+
+struct dcp_profile
+{
+    char accession[DCP_PROFILE_ACC_SIZE];
+    unsigned core_size;
+    int entry_dist;
+    float epsilon;
+    std::vector<char> consensus;
+    std::vector<float> trans8;     // [8][M]
+    std::vector<float> match_dist; // [M][129]
+    float null_dist[DCP_NDIST];
+    float insert_dist[DCP_NDIST];
+};
+
+// calculate_occupancy + setup_entry_trans (protein_model.c:258-283,410-439)
+static void entry_scores(unsigned M, int entry_dist, float const *trans,
+                         float *entry)
+{
+    if (entry_dist == DCP_ENTRY_DIST_UNIFORM)
+    {
+        // imm_log(2.0 / (M * (M + 1))) * M  -- reproduced as written (:415)
+        float Mf = (float)M;
+        float cost = (float)(std::log(2.0 / ((double)Mf * ((double)Mf + 1.0))) * (double)Mf);
+        for (unsigned i = 0; i < M; ++i)
+            entry[i] = cost;
+        return;
+    }
+    std::vector<double> locc(M);
+    auto T = [&](unsigned i, int f) { return (double)trans[7 * i + f]; };
+    enum { MM, MI, MD, IM, II, DM, DD };
+    locc[0] = logadd(T(0, MI), T(0, MM));
+    for (unsigned i = 1; i < M; ++i)
+    {
+        double v0 = locc[i - 1] + logadd(T(i, MM), T(i, MI));
+        double v1 = std::log1p(-std::exp(locc[i - 1])) + T(i, DM);
+        locc[i] = logadd(v0, v1);
+    }
+    double logZ = kNegInf;
+    for (unsigned i = 0; i < M; ++i)
+        logZ = logadd(logZ, locc[i] + std::log((double)(M - i)));
+    for (unsigned i = 0; i < M; ++i)
+        entry[i] = (float)(locc[i] - logZ);
+}
+
+extern "C" {
+
+dcp_profile *dcp_profile_new(char const *accession, unsigned core_size,
+                             int entry_dist, float epsilon,
+                             float const *null_lprobs,
+                             float const *match_lprobs, float const *trans,
+                             char const *consensus, int *rc)
+{
+    auto fail = [&](int code) -> dcp_profile * {
+        if (rc) *rc = code;
+        return nullptr;
+    };
+    if (core_size == 0 || core_size > DCP_CORE_SIZE_MAX) return fail(DCP_EINVAL);
+    if (!null_lprobs || !match_lprobs || !trans) return fail(DCP_EINVAL);
+    if (entry_dist != DCP_ENTRY_DIST_UNIFORM && entry_dist != DCP_ENTRY_DIST_OCCUPANCY)
+        return fail(DCP_EINVAL);
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail(DCP_EINVAL); // protein_cfg.h:18
+
+    dcp_profile *p = new (std::nothrow) dcp_profile();
+    if (!p) return fail(DCP_ENOMEM);
+    unsigned const M = core_size;
+    std::memset(p->accession, 0, sizeof p->accession);
+    if (accession) std::strncpy(p->accession, accession, sizeof p->accession - 1);
+    p->core_size = M;
+    p->entry_dist = entry_dist;
+    p->epsilon = epsilon;
+    p->consensus.assign(M + 1, '\0');
+    for (unsigned i = 0; i < M; ++i)
+        p->consensus[i] = consensus ? consensus[i] : '-';
+
+    // protein_model_init: null dist from the null amino lprobs, insert dist from
+    // all-zero log-odds (protein_model.c:122-127)
+    make_nuclt_dist(null_lprobs, p->null_dist);
+    float const zeros[20] = {0};
+    make_nuclt_dist(zeros, p->insert_dist);
+    // protein_model_add_node: match dist from lodds = lprob - null (:60-66)
+    p->match_dist.resize((size_t)M * DCP_NDIST);
+    for (unsigned k = 0; k < M; ++k)
+    {
+        float lodds[20];
+        for (int i = 0; i < 20; ++i)
+            lodds[i] = match_lprobs[k * 20 + i] - null_lprobs[i];
+        make_nuclt_dist(lodds, &p->match_dist[(size_t)k * DCP_NDIST]);
+    }
+
+    // setup_transitions (:460-500) folded into per-destination-node rows.
+    // trans[j] (j = i+1) carries the edges between node i and node i+1 and the
+    // MI/II edges of node i (:469-489).  B->M1 = trans[0].MM and M_M->E =
+    // trans[M].MM are overwritten by entry / exit scores (:421,:433,:448).
+    enum { MM, MI, MD, IM, II, DM, DD };
+    p->trans8.assign((size_t)8 * M, kNegInfF);
+    float *t8 = p->trans8.data();
+    entry_scores(M, entry_dist, trans, t8 + DCP_T_ENTRY * M);
+    for (unsigned i = 0; i + 1 < M; ++i)
+    {
+        float const *t = trans + 7 * (i + 1);
+        t8[DCP_T_MI * M + i] = t[MI];
+        t8[DCP_T_II * M + i] = t[II];
+        t8[DCP_T_MM * M + i + 1] = t[MM];
+        t8[DCP_T_IM * M + i + 1] = t[IM];
+        t8[DCP_T_MD * M + i + 1] = t[MD];
+        t8[DCP_T_DD * M + i + 1] = t[DD];
+        t8[DCP_T_DM * M + i + 1] = t[DM];
+    }
+    if (rc) *rc = DCP_OK;
+    return p;
+}
+
+dcp_profile *dcp_profile_sample(char const *accession, unsigned seed,
+                                unsigned core_size, int entry_dist,
+                                float epsilon, int *rc)
+{
+    if (core_size < 2 || core_size > DCP_CORE_SIZE_MAX) // assert(core_size >= 2) :262
+    {
+        if (rc) *rc = DCP_EINVAL;
+        return nullptr;
+    }
+    Rnd rnd(seed);
+    unsigned const M = core_size;
+    float null_lp[20];
+    sample_normalized(rnd, 20, null_lp, nullptr, 0);
+    std::vector<float> match((size_t)20 * M), trans((size_t)7 * (M + 1));
+    for (unsigned k = 0; k < M; ++k)
+        sample_normalized(rnd, 20, &match[(size_t)20 * k], nullptr, 0);
+    for (unsigned i = 0; i <= M; ++i)
+    {
+        int zero[2] = {6 /*DD*/, 2 /*MD*/};
+        int nz = i == 0 ? 1 : (i == M ? 2 : 0);
+        sample_normalized(rnd, 7, &trans[(size_t)7 * i], zero, nz);
+    }
+    return dcp_profile_new(accession, M, entry_dist, epsilon, null_lp,
+                           match.data(), trans.data(), nullptr, rc);
+}
+
+void dcp_profile_del(dcp_profile *p) { delete p; }
+unsigned dcp_profile_core_size(dcp_profile const *p) { return p->core_size; }
+char const *dcp_profile_accession(dcp_profile const *p) { return p->accession; }
+float const *dcp_profile_trans8(dcp_profile const *p) { return p->trans8.data(); }
+float const *dcp_profile_null_dist(dcp_profile const *p) { return p->null_dist; }
+float const *dcp_profile_insert_dist(dcp_profile const *p) { return p->insert_dist; }
+float const *dcp_profile_match_dist(dcp_profile const *p) { return p->match_dist.data(); }
+float dcp_profile_epsilon(dcp_profile const *p) { return p->epsilon; }
+
+// Frame-state emission in the probability domain (imm frame state; the 4-event
+// indel model of SURVEY Appendix A).  b = base probs, C = codon marginals.
+void dcp_frame_table_host(float const dist[DCP_NDIST], float epsilon,
+                          float out[DCP_NCODES])
+{
+    double b[4], C[125];
+    for (int i = 0; i < 4; ++i)
+        b[i] = std::exp((double)dist[i]);
+    for (int i = 0; i < 125; ++i)
+        C[i] = std::exp((double)dist[4 + i]);
+    double const e = (double)epsilon, f = 1.0 - (double)epsilon;
+    double const e2 = e * e, f2 = f * f;
+    auto c3 = [&](int x, int y, int z) { return C[x * 25 + y * 5 + z]; };
+    auto s1 = [&](int x) { return c3(x, 4, 4) + c3(4, x, 4) + c3(4, 4, x); };
+    auto s2 = [&](int x, int y) { return c3(4, x, y) + c3(x, 4, y) + c3(x, y, 4); };
+
+    for (int x = 0; x < 4; ++x)
+        out[x] = (float)std::log(e2 * f2 / 3.0 * s1(x));
+    for (int v = 0; v < 16; ++v)
+    {
+        int x1 = v >> 2, x2 = v & 3;
+        double p = 2.0 * e * f2 * f / 3.0 * s2(x1, x2) +
+                   e2 * e * f / 3.0 * (b[x2] * s1(x1) + b[x1] * s1(x2));
+        out[4 + v] = (float)std::log(p);
+    }
+    for (int v = 0; v < 64; ++v)
+    {
+        int x1 = v >> 4, x2 = (v >> 2) & 3, x3 = v & 3;
+        double p = f2 * f2 * c3(x1, x2, x3) +
+                   4.0 * e2 * f2 / 9.0 *
+                       (b[x1] * s2(x2, x3) + b[x2] * s2(x1, x3) + b[x3] * s2(x1, x2)) +
+                   e2 * e2 / 9.0 *
+                       (b[x1] * b[x2] * s1(x3) + b[x1] * b[x3] * s1(x2) +
+                        b[x2] * b[x3] * s1(x1));
+        out[20 + v] = (float)std::log(p);
+    }
+    for (int v = 0; v < 256; ++v)
+    {
+        int x[4] = {v >> 6, (v >> 4) & 3, (v >> 2) & 3, v & 3};
+        double one = b[x[0]] * c3(x[1], x[2], x[3]) + b[x[1]] * c3(x[0], x[2], x[3]) +
+                     b[x[2]] * c3(x[0], x[1], x[3]) + b[x[3]] * c3(x[0], x[1], x[2]);
+        double two = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+            {
+                int r[2], n = 0;
+                for (int k = 0; k < 4; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                two += b[x[i]] * b[x[j]] * s2(r[0], r[1]);
+            }
+        out[84 + v] = (float)std::log(e * f2 * f / 2.0 * one + e2 * e * f / 9.0 * two);
+    }
+    for (int v = 0; v < 1024; ++v)
+    {
+        int x[5] = {v >> 8, (v >> 6) & 3, (v >> 4) & 3, (v >> 2) & 3, v & 3};
+        double s = 0;
+        for (int i = 0; i < 5; ++i)
+            for (int j = i + 1; j < 5; ++j)
+            {
+                int r[3], n = 0;
+                for (int k = 0; k < 5; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                s += b[x[i]] * b[x[j]] * c3(r[0], r[1], r[2]);
+            }
+        out[340 + v] = (float)std::log(e2 * f2 / 10.0 * s);
+    }
+}
+
+// protein_profile_setup (protein_profile.c:155-216)
+int dcp_xtrans(unsigned seq_size, int multi_hits, int hmmer3_compat,
+               float out[DCP_NXTRANS])
+{
+    if (seq_size == 0) return DCP_EINVAL;
+    float const L = (float)seq_size;
+    float q = 0.0f, log_q = kNegInfF;
+    if (multi_hits)
+    {
+        q = 0.5f;
+        log_q = (float)std::log(0.5);
+    }
+    float lp = (float)std::log((double)L) - (float)std::log((double)(L + 2 + q / (1 - q)));
+    float l1p = (float)std::log((double)(2 + q / (1 - q))) -
+                (float)std::log((double)(L + 2 + q / (1 - q)));
+    float lr = (float)std::log((double)L) - (float)std::log((double)(L + 1));
+    float NN = lp, CC = lp, JJ = lp, NB = l1p, CT = l1p, JB = l1p, RR = lr;
+    float EJ = log_q, EC = (float)std::log((double)(1 - q));
+    if (hmmer3_compat) NN = CC = JJ = 0.0f;
+    out[DCP_X_RR] = RR;
+    out[DCP_X_SB] = NB;
+    out[DCP_X_SN] = NN;
+    out[DCP_X_NN] = NN;
+    out[DCP_X_NB] = NB;
+    out[DCP_X_ET] = EC + CT;
+    out[DCP_X_EC] = EC + CC;
+    out[DCP_X_CC] = CC;
+    out[DCP_X_CT] = CT;
+    out[DCP_X_EB] = EJ + JB;
+    out[DCP_X_EJ] = EJ + JJ;
+    out[DCP_X_JJ] = JJ;
+    out[DCP_X_JB] = JB;
+    return DCP_OK;
+}
+
+float dcp_lrt(float null_loglik, float alt_loglik)
+{
+    return -2 * (null_loglik - alt_loglik);
+}
+
+// xmath_partition_size (xmath.h:24-30) + partition_it (profile_reader.c:54-72)
+unsigned dcp_partition_by_count(unsigned nprofiles, unsigned npartitions,
+                                unsigned part_size[DCP_NUM_THREADS])
+{
+    if (npartitions == 0 || npartitions > DCP_NUM_THREADS) return 0;
+    unsigned nparts = npartitions < nprofiles ? npartitions : nprofiles;
+    for (unsigned i = 0; i < DCP_NUM_THREADS; ++i)
+        part_size[i] = 0;
+    if (nparts == 0) return 0;
+    unsigned i = 0, size = 0;
+    unsigned const chunk = (nprofiles + nparts - 1) / nparts;
+    for (unsigned j = 0; j < nprofiles; ++j)
+    {
+        unsigned want = chunk * i <= nprofiles
+                            ? (chunk < nprofiles - chunk * i ? chunk : nprofiles - chunk * i)
+                            : 0;
+        if (++size >= want)
+        {
+            part_size[i] = size;
+            ++i;
+            size = 0;
+            if (i >= nparts) break;
+        }
+    }
+    return nparts;
+}
+
+void dcp_partition_by_cells(unsigned const *core_sizes, unsigned nprofiles,
+                            unsigned npartitions, unsigned *part_begin)
+{
+    uint64_t total = 0;
+    for (unsigned i = 0; i < nprofiles; ++i)
+        total += core_sizes[i];
+    part_begin[0] = 0;
+    uint64_t acc = 0;
+    unsigned p = 0;
+    for (unsigned g = 1; g < npartitions; ++g)
+    {
+        // boundary g: first profile whose prefix sum reaches g/npartitions of the work
+        uint64_t target = (total * g + npartitions / 2) / npartitions;
+        while (p < nprofiles && acc + core_sizes[p] / 2 < target)
+            acc += core_sizes[p++];
+        part_begin[g] = p;
+    }
+    part_begin[npartitions] = nprofiles;
+}
+
+} // extern "C"

@@ -1,0 +1,221 @@
+/*
+ * dcp_gpu.h -- C-ABI of the MI355X-native profile-HMM scan engine.
+ *
+ * This is the drop-in boundary for deciphon-old's scan hot path
+ * (SURVEY.md §8b). Plain C: pointers, sizes, POD structs; no C++/torch types.
+ * Citations are `path:line` in the reference tree (EBI-Metagenomics/deciphon-old).
+ *
+ * What each group replaces:
+ *   dcp_profile_*        protein_profile_{init,sample,absorb,setup} and the model
+ *                        builder it calls   src/model/protein_profile.c:134-304,
+ *                                           src/model/protein_model.c:49-500
+ *   dcp_gpu_db_*         profile_reader_{setup,rewind,next} + protein_profile.unpack:
+ *                        the DB is uploaded ONCE and stays resident in HBM instead
+ *                        of being re-read per sequence
+ *                                           src/db/profile_reader.c:74-168,
+ *                                           src/model/protein_profile.c:38-117
+ *   dcp_gpu_seqs_*       imm_seq()/imm_task_setup(): sequence encoding, once per
+ *                        batch instead of once per (seq, profile) pair
+ *                                           src/server/scan.c:229,
+ *                                           src/server/scan_thread.c:51-55
+ *   dcp_gpu_scan*        thread_run's per-pair body: protein_profile_setup,
+ *                        imm_dp_viterbi(null), imm_dp_viterbi(alt), xmath_lrt filter
+ *                                           src/server/scan_thread.c:99-123,
+ *                                           include/deciphon/core/xmath.h:32-43
+ *
+ * Errors: every function that can fail returns `enum dcp_rc`, numerically equal
+ * to the reference's `enum rc` (include/deciphon/core/rc.h:4-15); HIP failures map
+ * to DCP_EFAIL and the message is kept in dcp_gpu_last_error().
+ * There is NO CPU fallback: without a HIP device dcp_gpu_ctx_new() fails.
+ */
+#ifndef DCP_GPU_H
+#define DCP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/deciphon/core/rc.h:4-15 */
+enum dcp_rc
+{
+    DCP_OK = 0,
+    DCP_END = 1,
+    DCP_EFAIL = 2,
+    DCP_EINVAL = 3,
+    DCP_EIO = 4,
+    DCP_ENOMEM = 5,
+    DCP_EPARSE = 6,
+    DCP_EAPI = 7,
+    DCP_EHTTP = 8,
+};
+
+/* include/deciphon/model/entry_dist.h:4-9 */
+enum dcp_entry_dist
+{
+    DCP_ENTRY_DIST_NULL = 0,
+    DCP_ENTRY_DIST_UNIFORM = 1,
+    DCP_ENTRY_DIST_OCCUPANCY = 2,
+};
+
+enum
+{
+    DCP_AMINO_SIZE = 20,          /* IMM_AMINO_SIZE */
+    DCP_TRANS_SIZE = 7,           /* PROTEIN_TRANS_SIZE, protein_trans.h:6 */
+    DCP_NCODES = 1364,            /* nucleotide words of length 1..5 */
+    DCP_NDIST = 129,              /* nuclt_dist: 4 base lprobs + 5x5x5 codon marg */
+    DCP_CORE_SIZE_MAX = 4096,     /* PROTEIN_MODEL_CORE_SIZE_MAX, limits.h:11 */
+    DCP_PROFILE_ACC_SIZE = 32,    /* limits.h:9 */
+    DCP_NUM_THREADS = 64,         /* limits.h:8: max partitions */
+    DCP_NXTRANS = 13,
+};
+
+/* ------------------------------------------------------------------------ */
+/* Host-side compact profile ("dcpx"): everything protein_profile carries     */
+/* that the scan needs, without the per-state emission tables (those are      */
+/* expanded on the device at upload).                                         */
+/* ------------------------------------------------------------------------ */
+typedef struct dcp_profile dcp_profile;
+
+/* protein_profile_init + protein_model_init/setup/add_node/add_trans +
+ * protein_profile_absorb (protein_profile.c:134-153,218-257;
+ * protein_model.c:49-137,155-184).
+ *   null_lprobs [20], match_lprobs [core_size][20] amino log-probs in
+ *   imm_amino_iupac order "ACDEFGHIKLMNPQRSTVWY"; trans [core_size+1][7] in
+ *   protein_trans order MM MI MD IM II DM DD (protein_trans.h:8-27).
+ * Returns NULL (and DCP_EINVAL in *rc) for core_size == 0 or > 4096,
+ * as protein_model_setup does (protein_model.c:157-160). */
+dcp_profile *dcp_profile_new(char const *accession, unsigned core_size,
+                             int entry_dist, float epsilon,
+                             float const *null_lprobs,
+                             float const *match_lprobs, float const *trans,
+                             char const *consensus, int *rc);
+
+/* protein_profile_sample (protein_profile.c:259-304): imm_rnd(seed) stream,
+ * log-uniform lprobs, normalised; DD=-inf at i=0, MD=DD=-inf at i=core_size. */
+dcp_profile *dcp_profile_sample(char const *accession, unsigned seed,
+                                unsigned core_size, int entry_dist,
+                                float epsilon, int *rc);
+void dcp_profile_del(dcp_profile *);
+unsigned dcp_profile_core_size(dcp_profile const *);
+char const *dcp_profile_accession(dcp_profile const *);
+
+/* Read-only views (host memory owned by the profile):
+ *   trans8 [8][core_size]: rows entry(B->Mk), MM, IM, DM, MD, DD (edges INTO
+ *   node k from node k-1) and MI, II (node k's own insert edges);
+ *   dists: null [129], insert [129], match [core_size][129]. */
+float const *dcp_profile_trans8(dcp_profile const *);
+float const *dcp_profile_null_dist(dcp_profile const *);
+float const *dcp_profile_insert_dist(dcp_profile const *);
+float const *dcp_profile_match_dist(dcp_profile const *);
+
+/* Frame-state emission table of one nuclt_dist over all 1364 words (host).
+ * out[code], code = {0,4,20,84,340}[len-1] + base-4 value of the word, first
+ * base most significant. Same formula the device expansion kernel evaluates. */
+void dcp_frame_table_host(float const dist[DCP_NDIST], float epsilon,
+                          float out[DCP_NCODES]);
+
+/* protein_profile_setup (protein_profile.c:155-216): the 13 length-dependent
+ * special transitions RR, SB, SN, NN, NB, ET, EC, CC, CT, EB, EJ, JJ, JB.
+ * DCP_EINVAL for seq_size == 0 (:158). */
+int dcp_xtrans(unsigned seq_size, int multi_hits, int hmmer3_compat,
+               float out[DCP_NXTRANS]);
+
+/* xmath_lrt_f32 (xmath.h:32-35) */
+float dcp_lrt(float null_loglik, float alt_loglik);
+
+/* profile_reader partitioning (profile_reader.c:54-72, xmath.h:24-30):
+ * contiguous count-balanced partitions. part_size[npart], returns npart =
+ * min(npartitions, nprofiles) or 0 on EINVAL (0 or > 64 partitions). */
+unsigned dcp_partition_by_count(unsigned nprofiles, unsigned npartitions,
+                                unsigned part_size[DCP_NUM_THREADS]);
+/* MI355X shard map: contiguous partitions balanced by sum of core sizes
+ * (cells), one per GPU. part_begin[npart+1]. */
+void dcp_partition_by_cells(unsigned const *core_sizes, unsigned nprofiles,
+                            unsigned npartitions, unsigned *part_begin);
+
+/* ------------------------------------------------------------------------ */
+/* Device context                                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct dcp_gpu_ctx dcp_gpu_ctx;
+
+int dcp_gpu_device_count(void);
+/* Fails (NULL) when no HIP device is present: there is no CPU fallback. */
+dcp_gpu_ctx *dcp_gpu_ctx_new(int device);
+void dcp_gpu_ctx_del(dcp_gpu_ctx *);
+char const *dcp_gpu_last_error(dcp_gpu_ctx const *);
+/* The HIP stream every launch of this context goes to (hipStream_t). */
+void *dcp_gpu_stream(dcp_gpu_ctx *);
+
+/* Upload `nprofiles` profiles; expands every match/insert/null frame-state
+ * emission table into HBM (layout: DESIGN.md §3). expand_on_host != 0 computes
+ * the tables with dcp_frame_table_host and copies them (slow; parity tests).
+ * Replaces any previously uploaded DB. */
+int dcp_gpu_db_upload(dcp_gpu_ctx *, dcp_profile *const *profiles,
+                      unsigned nprofiles, int expand_on_host);
+unsigned dcp_gpu_db_nprofiles(dcp_gpu_ctx const *);
+/* Copy profile p's expanded match table back: out [1364][core_size]. */
+int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *, unsigned p, float *out);
+
+/* Upload a batch of sequences. seqs: concatenated symbol ids 0..3 (A,C,G,T);
+ * seq_off[nseqs+1]. Any id > 3 or an empty sequence -> DCP_EINVAL
+ * (protein_profile.c:158; imm rejects symbols outside the alphabet). */
+int dcp_gpu_seqs_upload(dcp_gpu_ctx *, uint8_t const *seqs,
+                        uint32_t const *seq_off, unsigned nseqs);
+/* Same from ASCII "ACGT" text (what scan.c:229 hands to imm_seq). */
+int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *, char const *text,
+                             uint32_t const *seq_off, unsigned nseqs);
+unsigned dcp_gpu_nseqs(dcp_gpu_ctx const *);
+
+struct dcp_scan_params
+{
+    int multi_hits;      /* scan_thread.h:17 */
+    int hmmer3_compat;   /* scan_thread.h:18 */
+    float lrt_threshold; /* scan.c:221 passes 10.0 */
+    int keep_scores;     /* also keep dense null/alt score matrices */
+};
+
+/* scan_thread.c:121-123 keeps a pair iff lrt is finite and >= threshold */
+struct dcp_hit
+{
+    uint32_t seq_idx;
+    uint32_t profile_idx;
+    float null_loglik;
+    float alt_loglik;
+};
+
+/* Enqueue the scan of all resident sequences against all resident profiles on
+ * the context's stream (asynchronous). */
+int dcp_gpu_scan(dcp_gpu_ctx *, struct dcp_scan_params const *);
+/* Wait for the stream. */
+int dcp_gpu_sync(dcp_gpu_ctx *);
+/* Milliseconds between HIP events recorded on the context's stream around the
+ * kernels of the LAST dcp_gpu_scan (valid after dcp_gpu_sync). */
+float dcp_gpu_last_scan_ms(dcp_gpu_ctx *);
+/* Number of DP kernel launches of the last scan and sum of their cells. */
+unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
+
+/* Results of the last scan (synchronises).
+ * scores: null_out/alt_out [nseqs][nprofiles] (need keep_scores).
+ * hits: sorted by (seq_idx, profile_idx); returns count in *nhits; DCP_ENOMEM
+ * if cap is too small (nhits still set). */
+int dcp_gpu_fetch_scores(dcp_gpu_ctx *, float *null_out, float *alt_out);
+int dcp_gpu_fetch_hits(dcp_gpu_ctx *, struct dcp_hit *hits, unsigned cap,
+                       unsigned *nhits);
+/* Device pointers of the last scan's hit buffer/count (for an RCCL gather
+ * without a host round trip). */
+void *dcp_gpu_hits_device_ptr(dcp_gpu_ctx *);
+void *dcp_gpu_nhits_device_ptr(dcp_gpu_ctx *);
+
+/* Work accounting: alt-model DP cells = sum over pairs of core_size * L
+ * (the Gcell/s numerator) and the algorithmic bytes of SURVEY.md §8(d):
+ * sum over pairs of 20*M*L + 32*(M+1) + L + 8. */
+uint64_t dcp_gpu_scan_cells(dcp_gpu_ctx const *);
+uint64_t dcp_gpu_scan_algorithmic_bytes(dcp_gpu_ctx const *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

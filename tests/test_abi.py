@@ -1,0 +1,44 @@
+"""The C-ABI library loads and exports every symbol include/dcp_gpu.h declares.
+No compute is launched here (CPU-only suite)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dcp_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(dcp):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    lib = C.CDLL(dcp.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(dcp.ABI_SYMBOLS) == syms
+
+
+def test_no_oracle_in_product():
+    """The product tree must not reference the oracle (test infrastructure)."""
+    bad = []
+    prod = os.path.join(ROOT, "deciphon-old_amd")
+    for d, _, files in os.walk(prod):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"liboracle|oracle_py|oracle/|orc_[a-z]", txt):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_scanner_fails_loudly_without_gpu(dcp):
+    if dcp.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(dcp.DcpError):
+        dcp.Scanner(0)

@@ -1,0 +1,230 @@
+"""Parity of the HIP scan path against the CPU oracle (runs on a real MI355X).
+
+Two levels:
+  * DP level -- the oracle's float32 recursion is fed the PRODUCT's own tables
+    (transitions, emission tables, special transitions) and must match the
+    kernel BIT FOR BIT: every candidate is (pred + trans) + emis in IEEE float32
+    and only max combines them.
+  * end to end -- oracle builds everything itself (imm-style float32 log-domain
+    model build): scores agree within 5e-5 relative, the reference's own float32
+    bar (test/hope_support.h:26); tighter in practice.
+"""
+import numpy as np
+import pytest
+
+from oracle_py import ENTRY_DIST_OCCUPANCY, ENTRY_DIST_UNIFORM, encode
+
+pytestmark = pytest.mark.gpu
+
+REL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def scanner(dcp):
+    s = dcp.Scanner(0)
+    yield s
+    s.close()
+
+
+def rand_seqs(rng, n, lo, hi):
+    return [rng.integers(0, 4, int(rng.integers(lo, hi + 1)), dtype=np.uint8) for _ in range(n)]
+
+
+def oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, h3, expand_on_host):
+    """null/alt [nseq, nprof] from orc_dp_tables fed the tables the device holds."""
+    nl = np.zeros((len(seqs), len(profiles)), np.float32)
+    al = np.zeros_like(nl)
+    for p, prof in enumerate(profiles):
+        em = scanner.match_table(p)  # what the kernel reads
+        eps = prof_eps[id(prof)]
+        ei = dcp.frame_table_host(prof.insert_dist, eps)
+        en = dcp.frame_table_host(prof.null_dist, eps)
+        if expand_on_host:  # device copy must be the host table exactly
+            for k in (0, prof.core_size - 1):
+                assert np.array_equal(em[:, k], dcp.frame_table_host(prof.match_dist[k], eps))
+        for q, s in enumerate(seqs):
+            xt = dcp.xtrans(len(s), multi, h3)
+            rc, a, b = oracle32.dp_tables(prof.trans8, em, ei, en, xt, bytes(s))
+            assert rc == 0
+            nl[q, p], al[q, p] = a, b
+    return nl, al
+
+
+prof_eps = {}
+
+
+def make_profiles(dcp, specs):
+    out = []
+    for seed, M, entry, eps in specs:
+        p = dcp.ProteinProfile.sample(seed, M, dcp.ProteinCfg(entry, eps))
+        prof_eps[id(p)] = float(np.float32(eps))
+        out.append(p)
+    return out
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("multi,h3", [(True, False), (False, False), (True, True)])
+def test_dp_bit_exact_small(dcp, oracle32, scanner, multi, h3):
+    rng = np.random.default_rng(1)
+    specs = [(1, 2, ENTRY_DIST_UNIFORM, 0.1), (2, 2, ENTRY_DIST_OCCUPANCY, 0.01),
+             (3, 7, ENTRY_DIST_OCCUPANCY, 0.01), (4, 63, ENTRY_DIST_OCCUPANCY, 0.01),
+             (5, 64, ENTRY_DIST_UNIFORM, 0.01), (6, 65, ENTRY_DIST_OCCUPANCY, 0.01),
+             (7, 128, ENTRY_DIST_OCCUPANCY, 0.01), (8, 129, ENTRY_DIST_OCCUPANCY, 0.05),
+             (9, 192, ENTRY_DIST_OCCUPANCY, 0.01), (10, 200, ENTRY_DIST_OCCUPANCY, 0.01),
+             (11, 256, ENTRY_DIST_OCCUPANCY, 0.01)]
+    profiles = make_profiles(dcp, specs)
+    seqs = [np.array(list(encode("ATGAAACGCATTAGCACCACCATTACCACCAC")), np.uint8)]
+    seqs += [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 14, 15, 16, 17, 33, 64, 100, 301)]
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(multi, h3, 10.0)
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, h3, True)
+    assert same_bits(gn, on)
+    assert same_bits(ga, oa)
+    assert np.isfinite(ga).all() and np.isfinite(gn).all()
+
+
+def test_device_expansion_matches_host(dcp, scanner):
+    profiles = make_profiles(dcp, [(21, 5, ENTRY_DIST_OCCUPANCY, 0.01), (22, 70, ENTRY_DIST_UNIFORM, 0.1),
+                                   (23, 256, ENTRY_DIST_OCCUPANCY, 0.01)])
+    scanner.upload_db(profiles, expand_on_host=False)
+    for p, prof in enumerate(profiles):
+        em = scanner.match_table(p)
+        eps = prof_eps[id(prof)]
+        host = np.stack([dcp.frame_table_host(prof.match_dist[k], eps) for k in range(prof.core_size)], 1)
+        assert np.isfinite(em).all()
+        np.testing.assert_allclose(em, host, rtol=3e-7, atol=1e-6)
+
+
+def test_end_to_end_vs_oracle(dcp, oracle32, scanner):
+    """Device-expanded tables, oracle's independent float32 chain, incl. generic graph Viterbi."""
+    rng = np.random.default_rng(2)
+    specs = [(31, 2, ENTRY_DIST_UNIFORM, 0.1), (32, 17, ENTRY_DIST_OCCUPANCY, 0.01),
+             (33, 100, ENTRY_DIST_OCCUPANCY, 0.01), (34, 180, ENTRY_DIST_OCCUPANCY, 0.01),
+             (35, 256, ENTRY_DIST_UNIFORM, 0.01)]
+    profiles = make_profiles(dcp, specs)
+    seqs = rand_seqs(rng, 12, 20, 400)
+    scanner.upload_db(profiles)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0)
+    gn, ga = scanner.scores()
+    oprofs = [oracle32.sample(s, M, e, eps) for s, M, e, eps in specs]
+    hits, on, oa = oracle32.scan(oprofs, [bytes(s) for s in seqs], True, False, 10.0, nthreads=4, mode=1)
+    np.testing.assert_allclose(gn, on, rtol=REL, atol=0)
+    np.testing.assert_allclose(ga, oa, rtol=REL, atol=0)
+    # generic imm-style graph Viterbi on a subset
+    for p in (0, 2):
+        for q in (0, 5):
+            oprofs[p].setup(len(seqs[q]), True, False)
+            assert abs(oprofs[p].viterbi(1, bytes(seqs[q]), want_path=False)[1] - ga[q, p]) <= REL * abs(ga[q, p])
+            assert abs(oprofs[p].viterbi(0, bytes(seqs[q]), want_path=False)[1] - gn[q, p]) <= REL * abs(gn[q, p])
+
+
+def test_reference_goldens_through_the_gpu(dcp, scanner):
+    """test/protein_profile.c:41,65,157 on the HIP path, at the reference's float32 tolerance."""
+    seq = "ATGAAACGCATTAGCACCACCATTACCACCAC"
+    for entry, gold in ((ENTRY_DIST_UNIFORM, -55.59428153448), (ENTRY_DIST_OCCUPANCY, -54.35543421312)):
+        prof = dcp.ProteinProfile.sample(1, 2, dcp.ProteinCfg(entry, 0.1))
+        for host in (True, False):
+            scanner.upload_db([prof], expand_on_host=host)
+            scanner.upload_seqs([seq])
+            scanner.scan(True, False, 10.0)
+            nl, al = scanner.scores()
+            assert abs(nl[0, 0] - (-48.9272687711)) <= REL * 48.93
+            assert abs(al[0, 0] - gold) <= REL * abs(gold)
+            assert len(scanner.hits()) == 0  # lrt < 10
+
+
+def test_rejects_bad_sequences(dcp, scanner):
+    prof = dcp.ProteinProfile.sample(1, 2)
+    scanner.upload_db([prof])
+    with pytest.raises(dcp.DcpError) as e:  # protein_profile_setup(L=0) -> RC_EINVAL
+        scanner.upload_seqs([np.zeros(0, np.uint8)])
+    assert e.value.rc == dcp.RC_EINVAL
+    with pytest.raises(dcp.DcpError) as e:  # symbol outside the alphabet
+        scanner.upload_seqs(["ACGTNACGT"])
+    assert e.value.rc == dcp.RC_EINVAL
+    with pytest.raises(dcp.DcpError):
+        scanner.upload_seqs([])
+
+
+def planted_query(rng, oprof, prof_len, flank=30):
+    """A query carrying the most likely codon of each match state: a real hit."""
+    body = []
+    for k in range(prof_len):
+        best, arg = -np.inf, None
+        for c in range(64):
+            frag = bytes([(c >> 4) & 3, (c >> 2) & 3, c & 3])
+            lp, _ = oprof.decode(frag, (0 << 14) | (k + 1))
+            if lp > best:
+                best, arg = lp, frag
+        body.append(arg)
+    core = np.frombuffer(b"".join(body), np.uint8)
+    return np.concatenate([rng.integers(0, 4, flank, dtype=np.uint8), core,
+                           rng.integers(0, 4, flank, dtype=np.uint8)])
+
+
+def test_hits_and_lrt_filter(dcp, oracle32, scanner):
+    """Planted hits pass the LRT filter exactly where the oracle says (scan_thread.c:121-123)."""
+    rng = np.random.default_rng(3)
+    specs = [(41 + i, 40 + 13 * i, ENTRY_DIST_OCCUPANCY, 0.01) for i in range(6)]
+    profiles = make_profiles(dcp, specs)
+    oprofs = [oracle32.sample(s, M, e, eps) for s, M, e, eps in specs]
+    seqs = rand_seqs(rng, 10, 100, 300)
+    seqs[2] = planted_query(rng, oprofs[1], specs[1][1])
+    seqs[7] = planted_query(rng, oprofs[4], specs[4][1])
+    # multi-hit: two copies of the same domain in one query
+    seqs[9] = np.concatenate([planted_query(rng, oprofs[3], specs[3][1]), planted_query(rng, oprofs[3], specs[3][1])])
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    for multi in (True, False):
+        scanner.scan(multi, False, 10.0)
+        gn, ga = scanner.scores()
+        on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
+        assert same_bits(gn, on) and same_bits(ga, oa)
+        lrt = np.float32(-2) * (on - oa)
+        want = sorted((q, p) for q in range(len(seqs)) for p in range(len(profiles))
+                      if np.isfinite(lrt[q, p]) and lrt[q, p] >= 10.0)
+        hits = scanner.hits()
+        got = [(int(h["seq_idx"]), int(h["profile_idx"])) for h in hits]
+        assert got == want
+        assert (2, 1) in got and (7, 4) in got and (9, 3) in got
+        for h in hits:
+            assert h["null_loglik"] == on[h["seq_idx"], h["profile_idx"]]
+            assert h["alt_loglik"] == oa[h["seq_idx"], h["profile_idx"]]
+    # the two-domain query scores higher with multi-hit than without
+    scanner.scan(True, False, 10.0)
+    a_multi = scanner.scores()[1][9, 3]
+    scanner.scan(False, False, 10.0)
+    a_uni = scanner.scores()[1][9, 3]
+    assert a_multi > a_uni
+
+
+def test_scan_is_idempotent_and_order_free(dcp, scanner):
+    """Size-independent properties: same scores on re-scan, under profile permutation and
+    when the batch is split (pairs are independent)."""
+    rng = np.random.default_rng(4)
+    specs = [(51 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate(rng.integers(2, 257, 24))]
+    profiles = make_profiles(dcp, specs)
+    seqs = rand_seqs(rng, 40, 30, 250)
+    scanner.upload_db(profiles)
+    scanner.upload_seqs(seqs)
+    scanner.scan()
+    n1, a1 = scanner.scores()
+    scanner.scan()
+    n2, a2 = scanner.scores()
+    assert same_bits(n1, n2) and same_bits(a1, a2)
+    perm = rng.permutation(len(profiles))
+    scanner.upload_db([profiles[i] for i in perm])
+    scanner.scan()
+    n3, a3 = scanner.scores()
+    assert same_bits(n3, n1[:, perm]) and same_bits(a3, a1[:, perm])
+    scanner.upload_seqs(seqs[10:25])
+    scanner.scan()
+    n4, a4 = scanner.scores()
+    assert same_bits(n4, n1[10:25][:, perm]) and same_bits(a4, a1[10:25][:, perm])
