@@ -527,14 +527,13 @@ int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
         a.first_prof = first;
         a.nprof = last - first;
         SizeClass const sc = kClasses[k];
-        if (sc.W != 1)
-            return c->fail(DCP_EINVAL, "core_size > 256 not supported by this build");
+        uint64_t const tpb = dcp_rowsweep_tasks_per_block(sc.W);
         uint64_t ntasks = (uint64_t)a.nprof * a.nchunks;
-        uint64_t nblocks = (ntasks + 3) / 4;
+        uint64_t nblocks = (ntasks + tpb - 1) / tpb;
         nblocks = (nblocks + 7) / 8 * 8;
         if (nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
-        if (dcp_launch_rowsweep(sc.R, &a, (unsigned)nblocks, c->stream))
-            return c->fail(DCP_EFAIL, "no kernel for class R=%d", sc.R);
+        if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, c->stream))
+            return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
         c->last_launches++;
     }
     HIP_TRY(c, hipGetLastError());

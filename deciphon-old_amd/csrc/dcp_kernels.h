@@ -63,8 +63,9 @@ struct dcp_expand_args
 extern "C" {
 #endif
 void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
-int dcp_launch_rowsweep(int R, dcp_scan_args const *a, unsigned nblocks,
+int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
+unsigned dcp_rowsweep_tasks_per_block(int W);
 #ifdef __cplusplus
 }
 #endif

@@ -114,13 +114,28 @@ struct RowOut
     float E, C, Rn;
 };
 
+// Cross-wavefront exchange area of one block (W > 1 only).  Slots are indexed by
+// a running barrier counter so a fast wave never overwrites what a slow wave is
+// still reading: data written before barrier g lives in buffer g & 1 and is read
+// only between barriers g and g+1; flags rotate over three words.
+template <int W> struct Exchange
+{
+    float m[2][W], i[2][W], d[2][W], e[2][W];
+    int flag[3];
+};
+
 // One DP row. PH = j % 5 is compile-time so the history ring needs no moves.
-template <int R, int PH>
+// W == 1: the wavefront owns the whole profile. W > 1: wavefront `wave` owns
+// nodes [wave*64*R, (wave+1)*64*R) and exchanges boundary values through LDS.
+template <int R, int W, int PH>
 __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                                          float const (&em)[5][R],
                                          float const (&eN)[5],
                                          float const (&eI)[5],
-                                         float const *__restrict__ xt)
+                                         float const *__restrict__ xt,
+                                         Exchange<(W > 1 ? W : 1)> *xc,
+                                         unsigned wave, unsigned lane,
+                                         unsigned &gen)
 {
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5,
                   s4 = (PH + 1) % 5, s5 = PH;
@@ -146,39 +161,92 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     float const Rn = max5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
                           s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
 
-    // neighbours: node k-1 lives in the previous register, or the previous lane
-    float const m_left = lane_shr1(m[R - 1], ni);
-    float const i_left = lane_shr1(ins[R - 1], ni);
-
-    // delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
-    // a lane; across lanes iterate to the fixed point (exact, no reassociation)
-    float a[R], d[R];
-    a[0] = m_left + t.md[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r)
-        a[r] = m[r - 1] + t.md[r];
-    d[0] = a[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r)
-        d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
-    float d_left;
-    for (;;)
-    {
-        d_left = lane_shr1(d[R - 1], ni);
-        float const before = d[R - 1];
-        d[0] = fmaxf(a[0], d_left + t.dd[0]);
+    // Delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
+    // a lane; across lanes (and wavefronts) iterate to the fixed point, which
+    // is the sequential recurrence's unique solution -- exact, no reassociation.
+    float m_first = ni, i_first = ni, d_first = ni; // node k-1 of lane 0
+    float m_left = lane_shr1(m[R - 1], m_first);
+    float i_left = lane_shr1(ins[R - 1], i_first);
+    float a[R], d[R], d_left;
+    auto chain = [&]() {
+        a[0] = m_left + t.md[0];
 #pragma unroll
         for (int r = 1; r < R; ++r)
-            d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
-        if (!__any(d[R - 1] != before)) break;
-    }
+            a[r] = m[r - 1] + t.md[r];
+        for (;;)
+        {
+            d_left = lane_shr1(d[R - 1], d_first);
+            float const before = d[R - 1];
+            d[0] = fmaxf(a[0], d_left + t.dd[0]);
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+            if (!__any(d[R - 1] != before)) break;
+        }
+    };
+    auto lane_max = [&]() {
+        float e = fmaxf(m[0], d[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            e = fmaxf(e, fmaxf(m[r], d[r]));
+        return e;
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        d[r] = ni;
+    chain();
 
     // E = max over nodes of M_k and D_k (exit scores are 0: protein_model.c:441-458)
-    float e_lane = fmaxf(m[0], d[0]);
+    float E;
+    if constexpr (W == 1)
+    {
+        E = wave_max(lane_max());
+    }
+    else
+    {
+        float published = ni; // lane 63: the D value the next wave last saw
+        for (unsigned it = 0;; ++it, ++gen)
+        {
+            unsigned const buf = gen & 1u;
+            float const e_wave = wave_max(lane_max());
+            if (lane == 63)
+            {
+                if (it == 0)
+                {
+                    xc->m[buf][wave] = m[R - 1];
+                    xc->i[buf][wave] = ins[R - 1];
+                }
+                else if (d[R - 1] != published)
+                    xc->flag[gen % 3u] = 1;
+                xc->d[buf][wave] = d[R - 1];
+                xc->e[buf][wave] = e_wave;
+                published = d[R - 1];
+            }
+            if (threadIdx.x == 0) xc->flag[(gen + 1u) % 3u] = 0;
+            __syncthreads();
+            if (it > 0 && xc->flag[gen % 3u] == 0)
+            {
+                E = xc->e[buf][0];
 #pragma unroll
-    for (int r = 1; r < R; ++r)
-        e_lane = fmaxf(e_lane, fmaxf(m[r], d[r]));
-    float const E = wave_max(e_lane);
+                for (int w = 1; w < W; ++w)
+                    E = fmaxf(E, xc->e[buf][w]);
+                ++gen;
+                break;
+            }
+            if (wave > 0)
+            {
+                if (it == 0)
+                {
+                    m_first = xc->m[buf][wave - 1];
+                    i_first = xc->i[buf][wave - 1];
+                    m_left = lane_shr1(m[R - 1], m_first);
+                    i_left = lane_shr1(ins[R - 1], i_first);
+                }
+                d_first = xc->d[buf][wave - 1];
+            }
+            chain();
+        }
+    }
 
     // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf)
     float const B = fmaxf(fmaxf(N + xt[DCP_X_NB], E + xt[DCP_X_EB]), J + xt[DCP_X_JB]);
@@ -230,14 +298,19 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 } // namespace
 
 // ============================================================================
-// Exact row-sweep Viterbi, one wavefront per (profile, query) pair.
-// Lane t owns nodes [t*R, t*R+R) of the profile (core_size <= 64*R).
-// Block = 4 independent wavefronts working on consecutive query chunks of the
-// same profile (so their emission-table reads share one XCD's L2).
+// Exact row-sweep Viterbi.  Lane t of wavefront w owns nodes
+// [(w*64+t)*R, (w*64+t)*R + R) of the profile (core_size <= 64*R*W).
+//   W == 1: block = 4 independent wavefronts, each its own (profile, query
+//           chunk) task, consecutive chunks of the same profile so that their
+//           emission-table reads share one XCD's L2;
+//   W  > 1: block = W cooperating wavefronts on one task.
 // ============================================================================
-template <int R>
-__global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
+template <int R, int W>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
+    constexpr unsigned TASKS_PER_BLOCK = W == 1 ? 4u : 1u;
+    __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
+    Exchange<(W > 1 ? W : 1)> *xc = &xc_mem;
     unsigned const lane = threadIdx.x & 63u;
     unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -246,10 +319,10 @@ __global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
     // same few profiles).  Placement only affects speed, never results.
     unsigned const nblk = gridDim.x; // multiple of 8
     unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    unsigned const task = vblk * 4u + wave;
+    unsigned const task = W == 1 ? vblk * TASKS_PER_BLOCK + wave : vblk;
     unsigned const nchunks = a.nchunks;
     unsigned const slot = task / nchunks;
-    if (slot >= a.nprof) return;
+    if (slot >= a.nprof) return; // uniform per task: whole block for W > 1
     unsigned const chunk = task - slot * nchunks;
 
     dcp_prof_meta const pm = a.profs[a.first_prof + slot];
@@ -257,7 +330,13 @@ __global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
     float const *__restrict__ eN_tab = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
     float const *__restrict__ eI_tab = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
     unsigned const ldk = pm.ldk;
-    unsigned const lane_off = lane * R;
+    unsigned const lane_off = ((W == 1 ? 0u : wave * 64u) + lane) * R;
+    unsigned gen = 0;
+    if constexpr (W > 1)
+    {
+        if (threadIdx.x == 0) xc->flag[0] = xc->flag[1] = xc->flag[2] = 0;
+        __syncthreads();
+    }
 
     Trans<R> t;
     {
@@ -313,7 +392,7 @@ __global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
         load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, emn, eNn, eIn); \
-        o = dp_row<R, PH>(s, t, em, eN, eI, xt);                               \
+        o = dp_row<R, W, PH>(s, t, em, eN, eI, xt, xc, wave, lane, gen);       \
         _Pragma("unroll") for (int l = 0; l < 5; ++l)                          \
         {                                                                      \
             _Pragma("unroll") for (int r = 0; r < R; ++r) em[l][r] = emn[l][r]; \
@@ -333,7 +412,7 @@ __global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
 
         float const alt = fmaxf(o.E + xt[DCP_X_ET], o.C + xt[DCP_X_CT]);
         float const nul = o.Rn;
-        if (lane == 0)
+        if (threadIdx.x == (W == 1 ? wave * 64u : 0u))
         {
             size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
             if (a.out_null) a.out_null[oi] = nul;
@@ -349,11 +428,6 @@ __global__ __launch_bounds__(256) void viterbi_rowsweep_kernel(dcp_scan_args a)
         }
     }
 }
-
-template __global__ void viterbi_rowsweep_kernel<1>(dcp_scan_args);
-template __global__ void viterbi_rowsweep_kernel<2>(dcp_scan_args);
-template __global__ void viterbi_rowsweep_kernel<3>(dcp_scan_args);
-template __global__ void viterbi_rowsweep_kernel<4>(dcp_scan_args);
 
 // ============================================================================
 // Emission-table expansion: out[code][k] for a tile of 64 nodes per block.
@@ -469,18 +543,29 @@ extern "C" void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles,
                        (hipStream_t)stream, *a);
 }
 
-extern "C" int dcp_launch_rowsweep(int R, dcp_scan_args const *a, unsigned nblocks,
-                                   void *stream)
+template <int R, int W>
+static void launch_rs(dcp_scan_args const *a, unsigned nblocks, hipStream_t s)
 {
-    dim3 g(nblocks), b(256);
+    hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W>), dim3(nblocks),
+                       dim3(W == 1 ? 256 : 64 * W), 0, s, *a);
+}
+
+// tasks per block of the (R, W) kernel: 4 independent wavefronts when W == 1
+extern "C" unsigned dcp_rowsweep_tasks_per_block(int W) { return W == 1 ? 4u : 1u; }
+
+extern "C" int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a,
+                                   unsigned nblocks, void *stream)
+{
     hipStream_t s = (hipStream_t)stream;
-    switch (R)
-    {
-    case 1: hipLaunchKernelGGL(viterbi_rowsweep_kernel<1>, g, b, 0, s, *a); break;
-    case 2: hipLaunchKernelGGL(viterbi_rowsweep_kernel<2>, g, b, 0, s, *a); break;
-    case 3: hipLaunchKernelGGL(viterbi_rowsweep_kernel<3>, g, b, 0, s, *a); break;
-    case 4: hipLaunchKernelGGL(viterbi_rowsweep_kernel<4>, g, b, 0, s, *a); break;
-    default: return -1;
+#define DCP_CASE(r, w)                                                         \
+    if (R == r && W == w)                                                      \
+    {                                                                          \
+        launch_rs<r, w>(a, nblocks, s);                                        \
+        return 0;                                                              \
     }
-    return 0;
+    DCP_CASE(1, 1) DCP_CASE(2, 1) DCP_CASE(3, 1) DCP_CASE(4, 1)
+    DCP_CASE(3, 2) DCP_CASE(4, 2) DCP_CASE(3, 4) DCP_CASE(4, 4)
+    DCP_CASE(3, 8) DCP_CASE(4, 8) DCP_CASE(3, 16) DCP_CASE(4, 16)
+#undef DCP_CASE
+    return -1;
 }

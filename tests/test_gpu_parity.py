@@ -153,6 +153,27 @@ def test_rejects_bad_sequences(dcp, scanner):
         scanner.upload_seqs([])
 
 
+def pfam_like_params(rng, M):
+    """Peaked match distributions and Pfam-like transitions (MM ~ 0.95), so that a query
+    emitted from the consensus is a real hit."""
+    def norm(x):
+        return x - np.logaddexp.reduce(x, axis=-1, keepdims=True)
+
+    null = norm(np.log(rng.random(20) + 0.5)).astype(np.float32)
+    match = np.log(rng.random((M, 20)) * 0.02 + 1e-3)
+    match[np.arange(M), rng.integers(0, 20, M)] = np.log(0.8)
+    match = norm(match).astype(np.float32)
+    trans = np.tile(np.log(np.array([0.95, 0.025, 0.025, 0.6, 0.4, 0.6, 0.4])), (M + 1, 1))
+    trans[0, 6] = -np.inf
+    trans[M, 2] = trans[M, 6] = -np.inf
+    trans[:, 0:3] = norm(trans[:, 0:3])
+    trans[:, 3:5] = norm(trans[:, 3:5])
+    with np.errstate(invalid="ignore"):
+        dm = norm(trans[:, 5:7])
+    trans[:, 5:7] = np.where(np.isnan(dm), trans[:, 5:7], dm)
+    return null, match, trans.astype(np.float32)
+
+
 def planted_query(rng, oprof, prof_len, flank=30):
     """A query carrying the most likely codon of each match state: a real hit."""
     body = []
@@ -172,14 +193,18 @@ def planted_query(rng, oprof, prof_len, flank=30):
 def test_hits_and_lrt_filter(dcp, oracle32, scanner):
     """Planted hits pass the LRT filter exactly where the oracle says (scan_thread.c:121-123)."""
     rng = np.random.default_rng(3)
-    specs = [(41 + i, 40 + 13 * i, ENTRY_DIST_OCCUPANCY, 0.01) for i in range(6)]
-    profiles = make_profiles(dcp, specs)
-    oprofs = [oracle32.sample(s, M, e, eps) for s, M, e, eps in specs]
+    sizes = [40, 53, 66, 79, 92, 105]
+    params = [pfam_like_params(rng, M) for M in sizes]
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    for p in profiles:
+        prof_eps[id(p)] = cfg.epsilon
+    oprofs = [oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01) for prm in params]
     seqs = rand_seqs(rng, 10, 100, 300)
-    seqs[2] = planted_query(rng, oprofs[1], specs[1][1])
-    seqs[7] = planted_query(rng, oprofs[4], specs[4][1])
+    seqs[2] = planted_query(rng, oprofs[1], sizes[1])
+    seqs[7] = planted_query(rng, oprofs[4], sizes[4])
     # multi-hit: two copies of the same domain in one query
-    seqs[9] = np.concatenate([planted_query(rng, oprofs[3], specs[3][1]), planted_query(rng, oprofs[3], specs[3][1])])
+    seqs[9] = np.concatenate([planted_query(rng, oprofs[3], sizes[3]), planted_query(rng, oprofs[3], sizes[3])])
     scanner.upload_db(profiles, expand_on_host=True)
     scanner.upload_seqs(seqs)
     for multi in (True, False):
@@ -197,6 +222,10 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner):
         for h in hits:
             assert h["null_loglik"] == on[h["seq_idx"], h["profile_idx"]]
             assert h["alt_loglik"] == oa[h["seq_idx"], h["profile_idx"]]
+        # end to end against the oracle's own model build as well
+        _, en, ea = oracle32.scan(oprofs, [bytes(s) for s in seqs], multi, False, 10.0, 4, 1)
+        np.testing.assert_allclose(ga, ea, rtol=REL)
+        np.testing.assert_allclose(gn, en, rtol=REL)
     # the two-domain query scores higher with multi-hit than without
     scanner.scan(True, False, 10.0)
     a_multi = scanner.scores()[1][9, 3]
@@ -228,3 +257,66 @@ def test_scan_is_idempotent_and_order_free(dcp, scanner):
     scanner.scan()
     n4, a4 = scanner.scores()
     assert same_bits(n4, n1[10:25][:, perm]) and same_bits(a4, a1[10:25][:, perm])
+
+
+def delete_heavy_params(rng, M):
+    """Transitions that favour long delete runs (MD, DD large): the in-row delete chain then
+    carries across many lanes and wavefronts, the worst case for the fixed-point iteration."""
+    null, match, trans = pfam_like_params(rng, M)
+    t = np.tile(np.log(np.array([0.3, 0.05, 0.65, 0.5, 0.5, 0.08, 0.92])), (M + 1, 1))
+    t[0, 6] = -np.inf
+    t[M, 2] = t[M, 6] = -np.inf
+    return null, match, t.astype(np.float32)
+
+
+@pytest.mark.parametrize("sizes", [(257, 300, 384), (385, 512, 513), (700, 768, 1024),
+                                   (1025, 1536, 2048), (2049, 3072, 4096)])
+def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes):
+    """Multi-wavefront kernels (core_size > 256), incl. the maximum core size 4096
+    (PROTEIN_MODEL_CORE_SIZE_MAX, limits.h:11)."""
+    rng = np.random.default_rng(sum(sizes))
+    profiles = make_profiles(dcp, [(100 + i, M, ENTRY_DIST_OCCUPANCY, 0.01) for i, M in enumerate(sizes)])
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 4, 5, 6, 23, 60)]
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0)
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    assert same_bits(gn, on)
+    assert same_bits(ga, oa)
+
+
+@pytest.mark.parametrize("M", [40, 200, 256, 500, 1000, 2500])
+def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M):
+    rng = np.random.default_rng(M)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    prm = delete_heavy_params(rng, M)
+    prof = dcp.ProteinProfile.from_params(*prm, cfg)
+    prof_eps[id(prof)] = cfg.epsilon
+    oprof = oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01)
+    # a query made of the first and last few consensus codons: the best path must delete
+    # most of the profile in one run
+    head = planted_query(rng, oprof, 6, flank=0)
+    tail_codons = []
+    for k in range(M - 6, M):
+        best, arg = -np.inf, None
+        for c in range(64):
+            frag = bytes([(c >> 4) & 3, (c >> 2) & 3, c & 3])
+            lp, _ = oprof.decode(frag, k + 1)
+            if lp > best:
+                best, arg = lp, frag
+        tail_codons.append(arg)
+    jump = np.concatenate([head, np.frombuffer(b"".join(tail_codons), np.uint8)])
+    seqs = [jump, rng.integers(0, 4, 50, dtype=np.uint8), rng.integers(0, 4, 7, dtype=np.uint8)]
+    scanner.upload_db([prof], expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0)
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, [prof], seqs, True, False, True)
+    assert same_bits(gn, on)
+    assert same_bits(ga, oa)
+    # the generic graph Viterbi really uses a long delete run on the jump query
+    oprof.setup(len(jump), True, False)
+    _, _, path = oprof.viterbi(1, bytes(jump))
+    ndel = sum(1 for sid, _ in path if (sid >> 14) == 2)
+    assert ndel >= max(1, M - 16)
