@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gcell-updates/s of the profile-HMM scan (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[2] "Pfam-A-like 20k protein profiles x
+1 kbp queries": 20 000 sampled profiles (protein_profile_sample semantics, seeds 0xDEC1F0+p,
+core sizes clip(round(exp(N(ln 150, 0.6^2))), 30, 2000), seed 20000, OCCUPANCY entry, eps 0.01),
+uniform-ACGT 1 000-nt queries (seed 0x5E9+q), multi_hits, lrt threshold 10.  A step = one pass of
+the scan path over one batch of 1 000*N distinct queries against the whole (sharded) DB, inputs
+resident in HBM; 10 steps at N=1 are the full 10 000-query config.  With N ranks the DB is sharded
+by cells and the hits are all-gathered over RCCL each step (weak scaling: per-GPU pairs fixed).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_product():
+    name = "deciphon_old_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "deciphon-old_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+WORKLOADS = {
+    # name: (nprofiles, core-size rule, query length, queries per step per GPU, total queries)
+    "c3": dict(nprof=20000, qlen=1000, qstep=1000, label="C3 Pfam-A-like 20k profiles x 1 kbp queries"),
+    "c2": dict(nprof=1000, qlen=300, qstep=1000, label="C2 1k-profile synthetic DB x 300 bp queries"),
+}
+
+
+def core_sizes_for(workload, nprof):
+    if workload == "c2":
+        p = np.arange(nprof)
+        return (100 + (p * 37) % 201).astype(np.uint32)
+    rng = np.random.default_rng(20000)
+    return np.clip(np.round(np.exp(rng.normal(np.log(150.0), 0.6, nprof))), 30, 2000).astype(np.uint32)
+
+
+def make_queries(q_begin, q_end, qlen):
+    out = np.empty((q_end - q_begin, qlen), np.uint8)
+    for i, q in enumerate(range(q_begin, q_end)):
+        out[i] = np.random.default_rng(0x5E9 + q).integers(0, 4, qlen, dtype=np.uint8)
+    return out
+
+
+def cpu_baseline(dcp, sizes, workload, qlen, budget_s=15.0):
+    """The oracle (a from-scratch port of thread_run + imm_dp_viterbi; the reference itself cannot be
+    built here) timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_py import Oracle  # checker / baseline only
+
+    orc = Oracle(32)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(cores, 64)  # NUM_THREADS, limits.h:8
+    nprof = max(threads * 2, 16)
+    stride = max(1, len(sizes) // nprof)
+    pidx = list(range(0, len(sizes), stride))[:nprof]
+    profs = [orc.sample(0xDEC1F0 + p, int(sizes[p])) for p in pidx]
+    sumM = int(sum(int(sizes[p]) for p in pidx))
+    q = make_queries(0, 64, qlen)
+    # calibrate on one query, then size the sample for ~budget_s
+    t = time.perf_counter()
+    orc.scan(profs, [bytes(q[0])], True, False, 10.0, threads, 0)
+    dt1 = max(time.perf_counter() - t, 1e-3)
+    nq = int(max(1, min(64, budget_s / dt1)))
+    seqs = [bytes(q[i]) for i in range(nq)]
+    t = time.perf_counter()
+    orc.scan(profs, seqs, True, False, 10.0, threads, 0)
+    dt = time.perf_counter() - t
+    cells = sumM * nq * qlen
+    return {"value": round(cells / dt / 1e9, 4), "unit": "Gcell/s", "cores": threads, "kind": "port",
+            "sample": f"{len(pidx)} profiles (every {stride}th of the DB, sum M={sumM}) x {nq} queries x {qlen} nt, "
+                      f"generic graph Viterbi null+alt per pair (thread_run restatement), float32, "
+                      f"OpenMP schedule(static,1) over {threads} count-balanced partitions, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--nprof", type=int, default=0, help="override profile count (debug)")
+    ap.add_argument("--qstep", type=int, default=0, help="override queries per step per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dcp = load_product()
+    from deciphon_old_amd import dist as ddist
+
+    wl = WORKLOADS[args.workload]
+    nprof = args.nprof or wl["nprof"]
+    qlen = wl["qlen"]
+    qstep = (args.qstep or wl["qstep"]) * world
+    sizes = core_sizes_for(args.workload, nprof)
+
+    # ---- resident DB shard -------------------------------------------------------------
+    t0 = time.perf_counter()
+    b, e = ddist.shard_range(sizes, world, rank)
+    cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+    nthreads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
+    with ThreadPoolExecutor(max(1, nthreads // max(1, min(world, 8)))) as ex:
+        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
+                               range(b, e)))
+    t_build = time.perf_counter() - t0
+    sc = dcp.Scanner(local_rank)
+    t0 = time.perf_counter()
+    sc.upload_db(profiles)
+    t_upload = time.perf_counter() - t0
+    del profiles
+
+    # ---- resident queries: every step scans its own distinct batch --------------------------------
+    nsteps = args.steps + args.warmup
+    queries = make_queries(0, nsteps * qstep, qlen)
+    off = (np.arange(nsteps * qstep + 1, dtype=np.uint64) * qlen).astype(np.uint32)
+    sc.upload_seqs_flat(queries.reshape(-1), off)
+    del queries
+
+    cap = 1 << 16
+    hit_words = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+    hit_count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sc.set_hit_buffer(hit_words.data_ptr(), cap, hit_count.data_ptr())
+
+    def step(i):
+        sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep))
+        sc.sync()
+        if world > 1:
+            return ddist.gather_hits(hit_words, hit_count, b)
+        return None
+
+    def fence():
+        sc.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    per_class = {}
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nsteps):
+        step(i)
+        for li in sc.launch_infos():  # HIP events on the launch stream, read after the sync
+            k = (li["R"], li["W"])
+            acc = per_class.setdefault(k, dict(ms=0.0, bytes=0, cells=0, launches=0))
+            acc["ms"] += li["ms"]
+            acc["bytes"] += li["algorithmic_bytes"]
+            acc["cells"] += li["cells"]
+            acc["launches"] += 1
+            kernel_ms += li["ms"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    cells_rank = float(sum(v["cells"] for v in per_class.values()))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cc = torch.tensor([cells_rank], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        elapsed, cells_total = float(tt.item()), float(cc.item())
+    else:
+        cells_total = cells_rank
+
+    if rank == 0:
+        dom_key = max(per_class, key=lambda k: per_class[k]["ms"])
+        dom = per_class[dom_key]
+        dom_ms = dom["ms"] / dom["launches"]
+        dom_gbs = dom["bytes"] / dom["launches"] / (dom_ms * 1e-3) / 1e9
+        all_gbs = sum(v["bytes"] for v in per_class.values()) / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Gcell-updates/sec",
+            "value": round(cells_total / elapsed / 1e9, 3),
+            "unit": "Gcell/s",
+            "seqs_per_sec": round(args.steps * qstep / elapsed, 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{wl['label']}: {nprof} sampled profiles (sum M={int(sizes.sum())}, mean {sizes.mean():.0f}), "
+                            f"{qstep} distinct {qlen}-nt queries per step, multi_hits, lrt>=10",
+                "profiles_per_gpu": e - b, "queries_per_step": qstep, "query_len": qlen,
+                "parallelism": f"profile-shard x{world}" + (", RCCL hit all-gather per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>",
+                "achieved": round(dom_gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(dom_gbs / 8000.0, 4),
+                "traffic": None,
+                "avg_launch_ms": round(dom_ms, 3),
+                "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
+                "all_kernels_achieved": round(all_gbs, 1),
+                "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
+                "per_class_ms_per_step": {f"R{k[0]}W{k[1]}": round(v["ms"] / args.steps, 3) for k, v in sorted(per_class.items())},
+                "per_class_gcells_per_s": {f"R{k[0]}W{k[1]}": round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1)
+                                           for k, v in sorted(per_class.items())},
+            },
+            "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dcp, sizes, args.workload, qlen)
+        print(json.dumps(out))
+    sc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,8 +53,8 @@ ABI_SYMBOLS = [
     "dcp_gpu_db_upload", "dcp_gpu_db_nprofiles", "dcp_gpu_db_fetch_match_table",
     "dcp_gpu_seqs_upload", "dcp_gpu_seqs_upload_text", "dcp_gpu_nseqs", "dcp_gpu_scan",
     "dcp_gpu_sync", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
-    "dcp_gpu_fetch_hits", "dcp_gpu_hits_device_ptr", "dcp_gpu_nhits_device_ptr",
-    "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
+    "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
+    "dcp_gpu_last_scan_launch_info", "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
 ]
 
 
@@ -79,6 +79,11 @@ class ScanParams(C.Structure):
 class Hit(C.Structure):
     _fields_ = [("seq_idx", C.c_uint32), ("profile_idx", C.c_uint32),
                 ("null_loglik", C.c_float), ("alt_loglik", C.c_float)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("nodes_per_lane", C.c_int), ("waves_per_pair", C.c_int), ("nprofiles", C.c_uint),
+                ("ms", C.c_float), ("cells", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("seq_idx", np.uint32), ("profile_idx", np.uint32),
@@ -124,8 +129,9 @@ def _load():
         "dcp_gpu_last_scan_launches": (U, [P]),
         "dcp_gpu_fetch_scores": (I, [P, P, P]),
         "dcp_gpu_fetch_hits": (I, [P, P, U, C.POINTER(U)]),
-        "dcp_gpu_hits_device_ptr": (P, [P]),
-        "dcp_gpu_nhits_device_ptr": (P, [P]),
+        "dcp_gpu_scan_range": (I, [P, C.POINTER(ScanParams), U, U]),
+        "dcp_gpu_set_hit_buffer": (I, [P, P, U, P]),
+        "dcp_gpu_last_scan_launch_info": (I, [P, U, C.POINTER(LaunchInfo)]),
         "dcp_gpu_scan_cells": (C.c_uint64, [P]),
         "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
     }
@@ -338,11 +344,27 @@ class Scanner:
         self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
 
     def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
-             sync=True):
+             sync=True, q_range=None):
         prm = ScanParams(int(multi_hits), int(hmmer3_compat), float(lrt_threshold), int(keep_scores))
-        self._check(lib.dcp_gpu_scan(self._c, C.byref(prm)))
+        if q_range is None:
+            self._check(lib.dcp_gpu_scan(self._c, C.byref(prm)))
+        else:
+            self._check(lib.dcp_gpu_scan_range(self._c, C.byref(prm), q_range[0], q_range[1]))
         if sync:
             self.sync()
+
+    def set_hit_buffer(self, hits_dev_ptr, cap, nhits_dev_ptr):
+        """Route hit records into caller-owned device memory (e.g. a torch tensor for RCCL)."""
+        self._check(lib.dcp_gpu_set_hit_buffer(self._c, hits_dev_ptr, cap, nhits_dev_ptr))
+
+    def launch_infos(self):
+        out = []
+        for i in range(self.last_scan_launches):
+            li = LaunchInfo()
+            self._check(lib.dcp_gpu_last_scan_launch_info(self._c, i, C.byref(li)))
+            out.append(dict(R=li.nodes_per_lane, W=li.waves_per_pair, nprofiles=li.nprofiles,
+                            ms=li.ms, cells=li.cells, algorithmic_bytes=li.algorithmic_bytes))
+        return out
 
     def sync(self):
         self._check(lib.dcp_gpu_sync(self._c))

@@ -96,6 +96,15 @@ struct dcp_gpu_ctx
     bool have_scores = false;
     unsigned last_launches = 0;
     bool scanned = false;
+    unsigned last_q0 = 0, last_q1 = 0;
+    // caller-owned hit buffer (e.g. a torch tensor that RCCL gathers)
+    dcp_hit *ext_hits = nullptr;
+    unsigned *ext_nhits = nullptr;
+    unsigned ext_cap = 0;
+    // one HIP event after each size-class launch of the last scan
+    hipEvent_t ev_class[kNumClasses] = {nullptr};
+    int launched_class[kNumClasses] = {0};
+    unsigned n_launched = 0;
 
     int fail(int rc, char const *fmt, ...)
     {
@@ -151,6 +160,15 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         delete c;
         return nullptr;
     }
+    bool ok = true;
+    for (int k = 0; k < kNumClasses; ++k)
+        ok = ok && hipEventCreate(&c->ev_class[k]) == hipSuccess;
+    if (!ok)
+    {
+        fprintf(stderr, "dcp_gpu: failed to create stream/events on device %d\n", device);
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -161,6 +179,8 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (int k = 0; k < kNumClasses; ++k)
+        if (c->ev_class[k]) (void)hipEventDestroy(c->ev_class[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -449,9 +469,28 @@ int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *c, char const *text, uint32_t const *s
 // ---------------------------------------------------------------------------
 int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
 {
+    if (!c) return DCP_EINVAL;
+    return dcp_gpu_scan_range(c, prm, 0, c->nseqs);
+}
+
+int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *c, void *hits_dev, unsigned cap, void *nhits_dev)
+{
+    if (!c) return DCP_EINVAL;
+    if ((hits_dev == nullptr) != (nhits_dev == nullptr) || (hits_dev && cap == 0))
+        return c->fail(DCP_EINVAL, "hit buffer and counter must be given together");
+    c->ext_hits = (dcp_hit *)hits_dev;
+    c->ext_nhits = (unsigned *)nhits_dev;
+    c->ext_cap = hits_dev ? cap : 0;
+    return DCP_OK;
+}
+
+int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsigned q_begin,
+                       unsigned q_end)
+{
     if (!c || !prm) return DCP_EINVAL;
     if (c->nprof == 0) return c->fail(DCP_EINVAL, "no profile DB resident");
     if (c->nseqs == 0) return c->fail(DCP_EINVAL, "no sequences resident");
+    if (q_begin >= q_end || q_end > c->nseqs) return c->fail(DCP_EINVAL, "bad sequence range");
     HIP_TRY(c, hipSetDevice(c->device));
 
     // protein_profile_setup once per sequence instead of once per pair
@@ -489,12 +528,15 @@ int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
     }
     c->have_scores = prm->keep_scores != 0;
     unsigned want_cap = (unsigned)std::min<size_t>(npairs, (size_t)1 << 22);
-    if (c->hit_cap < want_cap)
+    if (!c->ext_hits && c->hit_cap < want_cap)
     {
         HIP_TRY(c, c->d_hits.alloc(want_cap));
         c->hit_cap = want_cap;
     }
     if (!c->d_nhits.p) HIP_TRY(c, c->d_nhits.alloc(1));
+    dcp_hit *const hits_p = c->ext_hits ? c->ext_hits : c->d_hits.p;
+    unsigned *const nhits_p = c->ext_hits ? c->ext_nhits : c->d_nhits.p;
+    unsigned const hits_cap = c->ext_hits ? c->ext_cap : c->hit_cap;
 
     dcp_scan_args a{};
     a.profs = c->d_metas.p;
@@ -503,23 +545,29 @@ int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
     a.emis_null = c->d_emis_null.p;
     a.trans8 = c->d_trans8.p;
     a.seq_words = c->d_seq_words.p;
-    a.seq_woff = c->d_seq_woff.p;
-    a.seq_len = c->d_seq_len.p;
-    a.xtrans = c->d_xtrans.p;
-    a.out_null = c->have_scores ? c->d_null.p : nullptr;
-    a.out_alt = c->have_scores ? c->d_alt.p : nullptr;
-    a.hits = c->d_hits.p;
-    a.nhits = c->d_nhits.p;
-    a.hit_cap = c->hit_cap;
+    // the kernels index sequences relative to q_begin
+    unsigned const nq = q_end - q_begin;
+    a.seq_woff = c->d_seq_woff.p + q_begin;
+    a.seq_len = c->d_seq_len.p + q_begin;
+    a.xtrans = c->d_xtrans.p + (size_t)q_begin * DCP_XSTRIDE;
+    a.out_null = c->have_scores ? c->d_null.p + (size_t)q_begin * c->nprof : nullptr;
+    a.out_alt = c->have_scores ? c->d_alt.p + (size_t)q_begin * c->nprof : nullptr;
+    a.hits = hits_p;
+    a.nhits = nhits_p;
+    a.hit_cap = hits_cap;
     a.lrt_threshold = prm->lrt_threshold;
     a.nprof_total = c->nprof;
-    a.nseqs = c->nseqs;
-    a.qchunk = c->nseqs >= 4096 ? 32u : (c->nseqs >= 256 ? 8u : 1u);
-    a.nchunks = (c->nseqs + a.qchunk - 1) / a.qchunk;
+    a.nseqs = nq;
+    a.q_base = q_begin;
+    a.qchunk = nq >= 4096 ? 32u : (nq >= 256 ? 8u : 1u);
+    a.nchunks = (nq + a.qchunk - 1) / a.qchunk;
+    c->last_q0 = q_begin;
+    c->last_q1 = q_end;
 
-    HIP_TRY(c, hipMemsetAsync(c->d_nhits.p, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(c, hipMemsetAsync(nhits_p, 0, sizeof(unsigned), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     c->last_launches = 0;
+    c->n_launched = 0;
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
@@ -534,6 +582,8 @@ int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
         if (nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, c->stream))
             return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
+        HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
+        c->launched_class[c->n_launched++] = k;
         c->last_launches++;
     }
     HIP_TRY(c, hipGetLastError());
@@ -561,6 +611,29 @@ float dcp_gpu_last_scan_ms(dcp_gpu_ctx *c)
 
 unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *c) { return c ? c->last_launches : 0; }
 
+int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_info *out)
+{
+    if (!c || !out || !c->scanned || i >= c->n_launched) return DCP_EINVAL;
+    int const k = c->launched_class[i];
+    hipEvent_t const before = i == 0 ? c->ev_start : c->ev_class[i - 1];
+    if (hipEventSynchronize(c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, before, c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
+    uint64_t sumM = 0, np = 0, len = 0;
+    for (unsigned j = c->class_first[k]; j < c->class_first[k + 1]; ++j, ++np)
+        sumM += c->metas[j].core_size;
+    for (unsigned q = c->last_q0; q < c->last_q1; ++q)
+        len += c->seq_len[q];
+    uint64_t const nq = c->last_q1 - c->last_q0;
+    out->nodes_per_lane = kClasses[k].R;
+    out->waves_per_pair = kClasses[k].W;
+    out->nprofiles = (unsigned)np;
+    out->ms = ms;
+    out->cells = sumM * len;
+    out->algorithmic_bytes = 20ull * sumM * len + 32ull * (sumM + np) * nq + len * np + 8ull * np * nq;
+    return DCP_OK;
+}
+
 int dcp_gpu_fetch_scores(dcp_gpu_ctx *c, float *null_out, float *alt_out)
 {
     if (!c) return DCP_EINVAL;
@@ -580,38 +653,47 @@ int dcp_gpu_fetch_hits(dcp_gpu_ctx *c, struct dcp_hit *hits, unsigned cap, unsig
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned n = 0;
-    HIP_TRY(c, hipMemcpy(&n, c->d_nhits.p, sizeof n, hipMemcpyDeviceToHost));
+    dcp_hit const *const hits_p = c->ext_hits ? c->ext_hits : c->d_hits.p;
+    unsigned const hits_cap = c->ext_hits ? c->ext_cap : c->hit_cap;
+    HIP_TRY(c, hipMemcpy(&n, c->ext_hits ? c->ext_nhits : c->d_nhits.p, sizeof n, hipMemcpyDeviceToHost));
     *nhits = n;
-    if (n > c->hit_cap) return c->fail(DCP_ENOMEM, "device hit buffer overflow: %u > %u", n, c->hit_cap);
+    if (n > hits_cap) return c->fail(DCP_ENOMEM, "device hit buffer overflow: %u > %u", n, hits_cap);
     if (n > cap || (n && !hits)) return DCP_ENOMEM;
     if (n == 0) return DCP_OK;
-    HIP_TRY(c, hipMemcpy(hits, c->d_hits.p, (size_t)n * sizeof(dcp_hit), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hits, hits_p, (size_t)n * sizeof(dcp_hit), hipMemcpyDeviceToHost));
     std::sort(hits, hits + n, [](dcp_hit const &x, dcp_hit const &y) {
         return x.seq_idx != y.seq_idx ? x.seq_idx < y.seq_idx : x.profile_idx < y.profile_idx;
     });
     return DCP_OK;
 }
 
-void *dcp_gpu_hits_device_ptr(dcp_gpu_ctx *c) { return c ? (void *)c->d_hits.p : nullptr; }
-void *dcp_gpu_nhits_device_ptr(dcp_gpu_ctx *c) { return c ? (void *)c->d_nhits.p : nullptr; }
+
+static void last_range(dcp_gpu_ctx const *c, uint64_t *sumM, uint64_t *len, uint64_t *nq)
+{
+    *sumM = *len = 0;
+    for (unsigned m : c->core_sizes)
+        *sumM += m;
+    unsigned q0 = c->scanned ? c->last_q0 : 0, q1 = c->scanned ? c->last_q1 : c->nseqs;
+    for (unsigned q = q0; q < q1; ++q)
+        *len += c->seq_len[q];
+    *nq = q1 - q0;
+}
 
 uint64_t dcp_gpu_scan_cells(dcp_gpu_ctx const *c)
 {
     if (!c) return 0;
-    uint64_t sumM = 0;
-    for (unsigned m : c->core_sizes)
-        sumM += m;
-    return sumM * c->total_len;
+    uint64_t sumM, len, nq;
+    last_range(c, &sumM, &len, &nq);
+    return sumM * len;
 }
 
 uint64_t dcp_gpu_scan_algorithmic_bytes(dcp_gpu_ctx const *c)
 {
     // per pair 20*M*L + 32*(M+1) + L + 8
     if (!c) return 0;
-    uint64_t sumM = 0, P = c->core_sizes.size(), Q = c->nseqs;
-    for (unsigned m : c->core_sizes)
-        sumM += m;
-    return 20ull * sumM * c->total_len + 32ull * (sumM + P) * Q + c->total_len * P + 8ull * P * Q;
+    uint64_t sumM, len, Q, P = c->core_sizes.size();
+    last_range(c, &sumM, &len, &Q);
+    return 20ull * sumM * len + 32ull * (sumM + P) * Q + len * P + 8ull * P * Q;
 }
 
 } // extern "C"

@@ -35,7 +35,8 @@ struct dcp_scan_args
     unsigned first_prof; // first entry of profs[] in this launch's size class
     unsigned nprof;      // profiles in this launch
     unsigned nprof_total;
-    unsigned nseqs;
+    unsigned nseqs;  // sequences in this launch (arrays already offset to the first)
+    unsigned q_base; // index of the first one in the resident batch (hit records)
     unsigned qchunk;  // queries per task
     unsigned nchunks; // ceil(nseqs / qchunk)
 };

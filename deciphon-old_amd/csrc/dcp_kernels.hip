@@ -423,7 +423,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
             {
                 unsigned const h = atomicAdd(a.nhits, 1u);
                 if (h < a.hit_cap)
-                    a.hits[h] = dcp_hit{q, pm.pidx, nul, alt};
+                    a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
             }
         }
     }

@@ -189,13 +189,38 @@ struct dcp_hit
 /* Enqueue the scan of all resident sequences against all resident profiles on
  * the context's stream (asynchronous). */
 int dcp_gpu_scan(dcp_gpu_ctx *, struct dcp_scan_params const *);
+/* Same for the resident sequences [q_begin, q_end): scan.c:227-258 hands
+ * thread_run one sequence at a time; a caller that prefetched N sequences scans
+ * them batch by batch without re-uploading. Hits and scores keep the indices
+ * of the resident batch. */
+int dcp_gpu_scan_range(dcp_gpu_ctx *, struct dcp_scan_params const *,
+                       unsigned q_begin, unsigned q_end);
+/* Let the scan write its hit records and hit count into caller-owned DEVICE
+ * memory (cap records of struct dcp_hit, one uint32 counter) -- e.g. a buffer
+ * that RCCL then gathers. NULL, 0, NULL restores the internal
+ * buffer. */
+int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *, void *hits_dev, unsigned cap,
+                           void *nhits_dev);
 /* Wait for the stream. */
 int dcp_gpu_sync(dcp_gpu_ctx *);
 /* Milliseconds between HIP events recorded on the context's stream around the
  * kernels of the LAST dcp_gpu_scan (valid after dcp_gpu_sync). */
 float dcp_gpu_last_scan_ms(dcp_gpu_ctx *);
-/* Number of DP kernel launches of the last scan and sum of their cells. */
+/* Number of DP kernel launches of the last scan (one per profile size class). */
 unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
+/* Launch i of the last scan: its kernel shape, HIP-event duration on the
+ * context's stream, DP cells and algorithmic bytes. */
+struct dcp_launch_info
+{
+    int nodes_per_lane; /* R */
+    int waves_per_pair; /* W */
+    unsigned nprofiles;
+    float ms;
+    uint64_t cells;
+    uint64_t algorithmic_bytes;
+};
+int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *, unsigned i,
+                                  struct dcp_launch_info *out);
 
 /* Results of the last scan (synchronises).
  * scores: null_out/alt_out [nseqs][nprofiles] (need keep_scores).
@@ -204,14 +229,10 @@ unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
 int dcp_gpu_fetch_scores(dcp_gpu_ctx *, float *null_out, float *alt_out);
 int dcp_gpu_fetch_hits(dcp_gpu_ctx *, struct dcp_hit *hits, unsigned cap,
                        unsigned *nhits);
-/* Device pointers of the last scan's hit buffer/count (for an RCCL gather
- * without a host round trip). */
-void *dcp_gpu_hits_device_ptr(dcp_gpu_ctx *);
-void *dcp_gpu_nhits_device_ptr(dcp_gpu_ctx *);
-
-/* Work accounting: alt-model DP cells = sum over pairs of core_size * L
- * (the Gcell/s numerator) and the algorithmic bytes of SURVEY.md §8(d):
- * sum over pairs of 20*M*L + 32*(M+1) + L + 8. */
+/* Work accounting of the last scan (or of a full scan if none ran yet):
+ * alt-model DP cells = sum over pairs of core_size * L (the Gcell/s numerator)
+ * and the algorithmic bytes of SURVEY.md §8(d): sum over pairs of
+ * 20*M*L + 32*(M+1) + L + 8. */
 uint64_t dcp_gpu_scan_cells(dcp_gpu_ctx const *);
 uint64_t dcp_gpu_scan_algorithmic_bytes(dcp_gpu_ctx const *);
 

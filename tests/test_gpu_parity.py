@@ -310,13 +310,15 @@ def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M):
     seqs = [jump, rng.integers(0, 4, 50, dtype=np.uint8), rng.integers(0, 4, 7, dtype=np.uint8)]
     scanner.upload_db([prof], expand_on_host=True)
     scanner.upload_seqs(seqs)
-    scanner.scan(True, False, 10.0)
-    gn, ga = scanner.scores()
-    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, [prof], seqs, True, False, True)
-    assert same_bits(gn, on)
-    assert same_bits(ga, oa)
-    # the generic graph Viterbi really uses a long delete run on the jump query
-    oprof.setup(len(jump), True, False)
-    _, _, path = oprof.viterbi(1, bytes(jump))
-    ndel = sum(1 for sid, _ in path if (sid >> 14) == 2)
-    assert ndel >= max(1, M - 16)
+    for multi in (True, False):
+        scanner.scan(multi, False, 10.0)
+        gn, ga = scanner.scores()
+        on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, [prof], seqs, multi, False, True)
+        assert same_bits(gn, on)
+        assert same_bits(ga, oa)
+    if M == 40:
+        # uni-hit: the generic graph Viterbi really crosses the profile in one delete run
+        oprof.setup(len(jump), False, False)
+        _, _, path = oprof.viterbi(1, bytes(jump))
+        ndel = sum(1 for sid, _ in path if (sid >> 14) == 2)
+        assert ndel >= 20
