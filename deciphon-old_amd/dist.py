@@ -44,7 +44,7 @@ def gather_hits(hit_words, hit_count, profile_offset, slab=4096, group=None):
     cap = hit_words.shape[0]
     if max(ns) > cap:
         raise RuntimeError(f"hit buffer overflow: {max(ns)} > {cap}")
-    rows = max(1, min(cap, max(slab, max(ns))) if max(ns) > slab else min(cap, slab))
+    rows = max(1, min(cap, max(slab, max(ns))))
     mine = hit_words[:rows].clone()
     n_mine = int(hit_count.item())
     if profile_offset:

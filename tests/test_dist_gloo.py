@@ -1,0 +1,82 @@
+"""Multi-GPU layer on CPU: world_size-2 gloo processes.
+
+The scan itself needs a GPU (no CPU fallback), so here the N>1 logic is covered with what does
+not: shard maps agree across ranks and tile the DB; the hit gather returns the union of every
+rank's records, remapped to global profile indices and sorted, identically on all ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_product
+
+    dcp = load_product()
+    from deciphon_old_amd import dist as ddist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        sizes = np.clip(np.round(np.exp(rng.normal(np.log(150), 0.6, 999))), 30, 2000).astype(np.uint32)
+        b, e = ddist.shard_range(sizes, world, rank)
+        bounds = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(bounds, torch.tensor([b, e]))
+        bounds = [tuple(int(x) for x in t) for t in bounds]
+        assert bounds[0][0] == 0 and bounds[-1][1] == len(sizes)
+        assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+        loads = [int(sizes[x:y].sum()) for x, y in bounds]
+        assert max(loads) - min(loads) <= 2 * int(sizes.max())
+
+        # every rank fabricates the hits "its shard" produced (shard-local profile indices)
+        def local_hits(r, n):
+            g = np.random.default_rng(100 + r)
+            h = np.zeros(n, dcp.HIT_DTYPE)
+            h["seq_idx"] = g.integers(0, 50, n)
+            h["profile_idx"] = g.permutation(bounds[r][1] - bounds[r][0])[:n]
+            h["null_loglik"] = -g.random(n).astype(np.float32) * 1000
+            h["alt_loglik"] = h["null_loglik"] + 20
+            return h
+
+        for counts in ([3, 5], [0, 4], [0, 0], [40, 2]):
+            n = counts[rank]
+            cap = 64
+            words = torch.zeros((cap, 4), dtype=torch.int32)
+            mine = local_hits(rank, n)
+            if n:
+                words[:n] = torch.from_numpy(mine.view(np.int32).reshape(n, 4))
+            got = ddist.gather_hits(words, torch.tensor([n], dtype=torch.int32), b, slab=8)
+            want = []
+            for r in range(world):
+                h = local_hits(r, counts[r]).copy()
+                h["profile_idx"] += bounds[r][0]
+                want.append(h)
+            want = np.concatenate(want)
+            want = want[np.lexsort((want["profile_idx"], want["seq_idx"]))]
+            assert got.dtype == dcp.HIT_DTYPE and len(got) == sum(counts)
+            assert np.array_equal(got, want)
+            assert (got["profile_idx"] < len(sizes)).all()
+        # overflow is an error, not silent truncation
+        try:
+            ddist.gather_hits(torch.zeros((4, 4), dtype=torch.int32), torch.tensor([9], dtype=torch.int32), b)
+            raise AssertionError("overflow not detected")
+        except RuntimeError:
+            pass
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
