@@ -223,7 +223,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>",
+                "kernel": (f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>" if dom_key[1] else
+                           f"viterbi_qlane_kernel<G={dom_key[0] // 4}>"),
                 "achieved": round(dom_gbs, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(dom_gbs / 8000.0, 4),
                 "traffic": None,
@@ -231,9 +232,10 @@ def main():
                 "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
                 "all_kernels_achieved": round(all_gbs, 1),
                 "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
-                "per_class_ms_per_step": {f"R{k[0]}W{k[1]}": round(v["ms"] / args.steps, 3) for k, v in sorted(per_class.items())},
-                "per_class_gcells_per_s": {f"R{k[0]}W{k[1]}": round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1)
-                                           for k, v in sorted(per_class.items())},
+                "per_class_ms_per_step": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"): round(v["ms"] / args.steps, 3)
+                                          for k, v in sorted(per_class.items())},
+                "per_class_gcells_per_s": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"):
+                                           round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in sorted(per_class.items())},
             },
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
         }

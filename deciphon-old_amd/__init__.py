@@ -73,7 +73,10 @@ def build(verbose=False):
 
 class ScanParams(C.Structure):
     _fields_ = [("multi_hits", C.c_int), ("hmmer3_compat", C.c_int),
-                ("lrt_threshold", C.c_float), ("keep_scores", C.c_int)]
+                ("lrt_threshold", C.c_float), ("keep_scores", C.c_int), ("kernel", C.c_int)]
+
+
+KERNEL_AUTO, KERNEL_ROWSWEEP, KERNEL_QLANE = 0, 1, 2
 
 
 class Hit(C.Structure):
@@ -344,8 +347,9 @@ class Scanner:
         self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
 
     def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
-             sync=True, q_range=None):
-        prm = ScanParams(int(multi_hits), int(hmmer3_compat), float(lrt_threshold), int(keep_scores))
+             sync=True, q_range=None, kernel=KERNEL_AUTO):
+        prm = ScanParams(int(multi_hits), int(hmmer3_compat), float(lrt_threshold), int(keep_scores),
+                         int(kernel))
         if q_range is None:
             self._check(lib.dcp_gpu_scan(self._c, C.byref(prm)))
         else:

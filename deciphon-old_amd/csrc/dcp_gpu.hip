@@ -79,6 +79,17 @@ struct dcp_gpu_ctx
     unsigned class_first[kNumClasses + 1] = {0};
     DevBuf<dcp_prof_meta> d_metas;
     DevBuf<float> d_emis_match, d_emis_insert, d_emis_null, d_trans8;
+    // query-lane kernel layout (dcp_qlane.hip)
+    int ql_G = 3; // nodes per tile = 4 * G
+    std::vector<dcp_ql_prof> ql_metas; // same order as metas
+    DevBuf<dcp_ql_prof> d_ql_metas;
+    DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
+    DevBuf<uint32_t> d_qorder;
+    DevBuf<unsigned> d_task_counter;
+    unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
+    unsigned num_cus = 0;
+    int last_kernel = 0; // 1 row sweep, 2 query lane
+    float last_ql_ms = 0;
 
     // resident sequences
     unsigned nseqs = 0;
@@ -159,6 +170,12 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         fprintf(stderr, "dcp_gpu: failed to create stream/events on device %d\n", device);
         delete c;
         return nullptr;
+    }
+    {
+        hipDeviceProp_t prop;
+        c->num_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? (unsigned)prop.multiProcessorCount : 256u;
+        char const *g = getenv("DCP_QLANE_G");
+        if (g && (atoi(g) == 2 || atoi(g) == 3)) c->ql_G = atoi(g);
     }
     bool ok = true;
     for (int k = 0; k < kNumClasses; ++k)
@@ -271,6 +288,49 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
 
+    // query-lane layout: per profile T = ceil(M / KT) tile images and per-tile transitions
+    unsigned const KT = 4u * (unsigned)c->ql_G;
+    uint64_t tile_floats = 0, ttrans_floats = 0;
+    c->ql_metas.assign(nprofiles, dcp_ql_prof{});
+    for (unsigned i = 0; i < nprofiles; ++i)
+    {
+        dcp_prof_meta const &m = c->metas[i];
+        dcp_ql_prof &qm = c->ql_metas[i];
+        qm.core_size = m.core_size;
+        qm.pidx = m.pidx;
+        qm.ntiles = (m.core_size + KT - 1) / KT;
+        qm.tile_off = tile_floats;
+        qm.ttrans_off = (uint32_t)ttrans_floats;
+        tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
+        ttrans_floats += (uint64_t)qm.ntiles * (KT + 1) * 8;
+    }
+    if (ttrans_floats > 0xffffffffull) return c->fail(DCP_EINVAL, "DB too large for 32-bit transition offsets");
+    HIP_TRY(c, c->d_ql_metas.alloc(nprofiles));
+    HIP_TRY(c, c->d_emis_tiles.alloc(tile_floats));
+    HIP_TRY(c, c->d_ttrans.alloc(ttrans_floats));
+    HIP_TRY(c, hipMemcpy(c->d_ql_metas.p, c->ql_metas.data(), nprofiles * sizeof(dcp_ql_prof), hipMemcpyHostToDevice));
+    {
+        float const ninf = -std::numeric_limits<float>::infinity();
+        std::vector<float> tt(ttrans_floats, ninf);
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_ql_prof const &qm = c->ql_metas[i];
+            float const *src = dcp_profile_trans8(profiles[qm.pidx]);
+            unsigned const M = qm.core_size;
+            for (unsigned t = 0; t < qm.ntiles; ++t)
+                for (unsigned kk = 0; kk <= KT; ++kk)
+                {
+                    unsigned node = t * KT + kk;
+                    if (node >= M) break;
+                    float *dst = &tt[qm.ttrans_off + ((size_t)t * (KT + 1) + kk) * 8];
+                    for (int row = 0; row < 8; ++row)
+                        dst[row] = src[(size_t)row * M + node];
+                }
+        }
+        HIP_TRY(c, hipMemcpy(c->d_ttrans.p, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->qorder_q0 = c->qorder_q1 = ~0u;
+
     if (expand_on_host)
     {
         // parity path: tables from dcp_frame_table_host, profile by profile
@@ -283,14 +343,22 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             dcp_profile const *pr = profiles[m.pidx];
             float eps = dcp_profile_epsilon(pr);
             tab.assign((size_t)DCP_NCODES * m.ldk, ninf);
+            dcp_ql_prof const &qm = c->ql_metas[i];
+            std::vector<float> img((size_t)qm.ntiles * KT * DCP_NCODES, ninf);
             float const *md = dcp_profile_match_dist(pr);
             for (unsigned k = 0; k < m.core_size; ++k)
             {
                 dcp_frame_table_host(md + (size_t)k * DCP_NDIST, eps, col.data());
+                size_t const grp = (size_t)(k / KT) * (KT / 4) + (k % KT) / 4;
                 for (unsigned code = 0; code < DCP_NCODES; ++code)
+                {
                     tab[(size_t)code * m.ldk + k] = col[code];
+                    img[(grp * DCP_NCODES + code) * 4 + (k & 3u)] = col[code];
+                }
             }
             HIP_TRY(c, hipMemcpy(c->d_emis_match.p + m.emis_off, tab.data(), tab.size() * sizeof(float),
+                                 hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->d_emis_tiles.p + qm.tile_off, img.data(), img.size() * sizeof(float),
                                  hipMemcpyHostToDevice));
             dcp_frame_table_host(dcp_profile_insert_dist(pr), eps, &ins[(size_t)m.pidx * DCP_NCODES]);
             dcp_frame_table_host(dcp_profile_null_dist(pr), eps, &nul[(size_t)m.pidx * DCP_NCODES]);
@@ -339,6 +407,24 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             }
         }
         size_t const n_match_tiles = tiles.size();
+        for (unsigned i = 0; i < nprofiles; ++i)
+        {
+            dcp_prof_meta const &m = c->metas[i];
+            dcp_ql_prof const &qm = c->ql_metas[i];
+            unsigned const ncol = qm.ntiles * KT; // incl. -inf padding nodes
+            for (unsigned k0 = 0; k0 < ncol; k0 += 64)
+            {
+                dcp_expand_tile t{};
+                t.out_off = qm.tile_off;
+                t.ncols = k0 < m.core_size ? std::min(64u, m.core_size - k0) : 0u;
+                t.dist_row = t.ncols ? dist_row[i] + k0 : 0u;
+                t.nstore = std::min(64u, ncol - k0);
+                t.kt = KT;
+                t.col0 = k0;
+                tiles.push_back(t);
+            }
+        }
+        size_t const n_image_tiles = tiles.size() - n_match_tiles;
         for (int which = 0; which < 2; ++which)
             for (unsigned p0 = 0; p0 < nprofiles; p0 += 64)
             {
@@ -350,7 +436,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
                 t.ld_col = DCP_NCODES;
                 tiles.push_back(t);
             }
-        size_t const n_special_tiles = (tiles.size() - n_match_tiles) / 2;
+        size_t const n_special_tiles = (tiles.size() - n_match_tiles - n_image_tiles) / 2;
 
         DevBuf<float> d_dists, d_eps;
         DevBuf<dcp_expand_tile> d_tiles;
@@ -363,9 +449,12 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         dcp_expand_args ea{d_tiles.p, d_dists.p, d_eps.p, c->d_emis_match.p};
         dcp_launch_expand(&ea, (unsigned)n_match_tiles, c->stream);
         ea.tiles = d_tiles.p + n_match_tiles;
+        ea.out = c->d_emis_tiles.p;
+        dcp_launch_expand(&ea, (unsigned)n_image_tiles, c->stream);
+        ea.tiles = d_tiles.p + n_match_tiles + n_image_tiles;
         ea.out = c->d_emis_insert.p;
         dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
-        ea.tiles = d_tiles.p + n_match_tiles + n_special_tiles;
+        ea.tiles = d_tiles.p + n_match_tiles + n_image_tiles + n_special_tiles;
         ea.out = c->d_emis_null.p;
         dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
         HIP_TRY(c, hipGetLastError());
@@ -564,10 +653,85 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->last_q0 = q_begin;
     c->last_q1 = q_end;
 
+    // kernel choice: the query-lane kernel needs enough queries to fill its lanes
+    int kernel = prm->kernel;
+    if (kernel == 0)
+    {
+        char const *f = getenv("DCP_KERNEL");
+        if (f && !strcmp(f, "rowsweep")) kernel = 1;
+        else if (f && !strcmp(f, "qlane")) kernel = 2;
+        else kernel = nq >= 128 ? 2 : 1;
+    }
+    c->last_kernel = kernel;
+    if (kernel == 2)
+    {
+        // queries sorted by length so that the lanes of a block finish together
+        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end)
+        {
+            std::vector<uint32_t> ord(nq);
+            for (unsigned i = 0; i < nq; ++i)
+                ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+                return c->seq_len[q_begin + x] < c->seq_len[q_begin + y];
+            });
+            unsigned lmax = 0;
+            for (unsigned q = q_begin; q < q_end; ++q)
+                lmax = std::max(lmax, c->seq_len[q]);
+            if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
+            HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax;
+        }
+        if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
+    }
+
     HIP_TRY(c, hipMemsetAsync(nhits_p, 0, sizeof(unsigned), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     c->last_launches = 0;
     c->n_launched = 0;
+    if (kernel == 2)
+    {
+        dcp_qlane_args qa{};
+        qa.profs = c->d_ql_metas.p;
+        qa.emis_tiles = c->d_emis_tiles.p;
+        qa.emis_insert = c->d_emis_insert.p;
+        qa.emis_null = c->d_emis_null.p;
+        qa.ttrans = c->d_ttrans.p;
+        qa.seq_words = a.seq_words;
+        qa.seq_woff = a.seq_woff;
+        qa.seq_len = a.seq_len;
+        qa.xtrans = a.xtrans;
+        qa.qorder = c->d_qorder.p;
+        qa.task_counter = c->d_task_counter.p;
+        qa.out_null = a.out_null;
+        qa.out_alt = a.out_alt;
+        qa.hits = hits_p;
+        qa.nhits = nhits_p;
+        qa.hit_cap = hits_cap;
+        qa.lrt_threshold = prm->lrt_threshold;
+        qa.nprof = c->nprof;
+        qa.nprof_total = c->nprof;
+        qa.nseqs = nq;
+        qa.q_base = q_begin;
+        qa.lmax = c->qorder_lmax;
+        qa.nqblocks = (nq + 255u) / 256u;
+        uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
+        if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
+        qa.ntasks = (unsigned)ntasks;
+        unsigned const nblocks = (unsigned)std::min<uint64_t>(ntasks, 2ull * c->num_cus);
+        size_t const need = (size_t)nblocks * 4u * qa.lmax * 256u;
+        if (c->d_scratch.n < need) HIP_TRY(c, c->d_scratch.alloc(need));
+        qa.scratch = c->d_scratch.p;
+        HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+        if (dcp_launch_qlane(c->ql_G, &qa, nblocks, c->stream))
+            return c->fail(DCP_EFAIL, "no query-lane kernel for G=%d", c->ql_G);
+        c->last_launches = 1;
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+        c->scanned = true;
+        return DCP_OK;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
@@ -613,7 +777,21 @@ unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *c) { return c ? c->last_l
 
 int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_info *out)
 {
-    if (!c || !out || !c->scanned || i >= c->n_launched) return DCP_EINVAL;
+    if (!c || !out || !c->scanned) return DCP_EINVAL;
+    if (c->last_kernel == 2)
+    {
+        if (i != 0) return DCP_EINVAL;
+        float ms = dcp_gpu_last_scan_ms(c);
+        if (ms < 0) return DCP_EFAIL;
+        out->nodes_per_lane = 4 * c->ql_G; // KT nodes per tile, one query per lane
+        out->waves_per_pair = 0;
+        out->nprofiles = c->nprof;
+        out->ms = ms;
+        out->cells = dcp_gpu_scan_cells(c);
+        out->algorithmic_bytes = dcp_gpu_scan_algorithmic_bytes(c);
+        return DCP_OK;
+    }
+    if (i >= c->n_launched) return DCP_EINVAL;
     int const k = c->launched_class[i];
     hipEvent_t const before = i == 0 ? c->ev_start : c->ev_class[i - 1];
     if (hipEventSynchronize(c->ev_class[i]) != hipSuccess) return DCP_EFAIL;

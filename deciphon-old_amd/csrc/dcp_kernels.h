@@ -50,6 +50,50 @@ struct dcp_expand_tile
     uint32_t nstore;   // columns to write (>= ncols: the rest is -inf padding)
     uint32_t ld_code;  // stride between consecutive codes
     uint32_t ld_col;   // stride between consecutive columns
+    // kt != 0: write the query-lane kernel's LDS tile image instead: column
+    // (= node) k of the profile goes to [k / kt][(k % kt) / 4][code][k % 4];
+    // out_off is then the profile's image base and col0 this tile's first node.
+    uint32_t kt;
+    uint32_t col0;
+};
+
+// ---- query-lane kernel (dcp_qlane.hip) --------------------------------------
+struct dcp_ql_prof
+{
+    uint64_t tile_off;   // float offset of the profile's tile images in emis_tiles
+    uint32_t ttrans_off; // float offset of its per-tile transitions [T][KT+1][8]
+    uint32_t core_size;
+    uint32_t ntiles;     // T = ceil(core_size / KT)
+    uint32_t pidx;
+};
+
+struct dcp_qlane_args
+{
+    dcp_ql_prof const *profs; // sorted by ascending size
+    float const *emis_tiles;  // per profile [T][G][1364][4]: the LDS image of each tile
+    float const *emis_insert; // [nprof_total][1364]
+    float const *emis_null;   // [nprof_total][1364]
+    float const *ttrans;      // per profile [T][KT+1][8] (row KT = edges into the next tile)
+    uint32_t const *seq_words;
+    uint32_t const *seq_woff;
+    uint32_t const *seq_len;
+    float const *xtrans;
+    uint32_t const *qorder;   // [nseqs] query indices sorted by length
+    float *scratch;           // [nblocks][4 planes][lmax][256]
+    unsigned *task_counter;
+    float *out_null;
+    float *out_alt;
+    dcp_hit *hits;
+    unsigned *nhits;
+    unsigned hit_cap;
+    float lrt_threshold;
+    unsigned nprof;
+    unsigned nprof_total;
+    unsigned nseqs;
+    unsigned q_base;
+    unsigned lmax;     // longest resident sequence of this scan
+    unsigned ntasks;   // nprof * nqblocks
+    unsigned nqblocks; // ceil(nseqs / 256)
 };
 
 struct dcp_expand_args
@@ -67,6 +111,7 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
+int dcp_launch_qlane(int G, dcp_qlane_args const *a, unsigned nblocks, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -526,12 +526,20 @@ __global__ __launch_bounds__(256) void expand_tables_kernel(dcp_expand_args a)
     __syncthreads();
     unsigned const k = threadIdx.x & 63u;
     double const e = k < nk ? (double)a.eps[tile.dist_row + k] : 0.0, f = 1.0 - e;
-    float *__restrict__ out = a.out + tile.out_off + (size_t)k * tile.ld_col;
+    size_t col_off = (size_t)k * tile.ld_col;
+    unsigned ld_code = tile.ld_code;
+    if (tile.kt)
+    {
+        unsigned const node = tile.col0 + k, kt = tile.kt;
+        col_off = ((size_t)(node / kt) * (kt / 4u) + (node % kt) / 4u) * (size_t)DCP_NCODES * 4u + (node & 3u);
+        ld_code = 4u;
+    }
+    float *__restrict__ out = a.out + tile.out_off + col_off;
     for (unsigned code = threadIdx.x >> 6; code < DCP_NCODES; code += 4u)
     {
         float v = -__builtin_inff(); // padding columns: unreachable nodes
         if (k < nk) v = (float)log(frame_prob(&lin[k][0], &lin[k][4], e, f, code));
-        if (k < tile.nstore) out[(size_t)code * tile.ld_code] = v;
+        if (k < tile.nstore) out[(size_t)code * ld_code] = v;
     }
 }
 

@@ -175,6 +175,9 @@ struct dcp_scan_params
     int hmmer3_compat;   /* scan_thread.h:18 */
     float lrt_threshold; /* scan.c:221 passes 10.0 */
     int keep_scores;     /* also keep dense null/alt score matrices */
+    int kernel;          /* 0 = choose by batch size; 1 = row sweep (one wavefront
+                          * group per pair: any batch size); 2 = query lane (one
+                          * lane per query, tiles in LDS: throughput path) */
 };
 
 /* scan_thread.c:121-123 keeps a pair iff lrt is finite and >= threshold */
@@ -212,8 +215,8 @@ unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
  * context's stream, DP cells and algorithmic bytes. */
 struct dcp_launch_info
 {
-    int nodes_per_lane; /* R */
-    int waves_per_pair; /* W */
+    int nodes_per_lane; /* row sweep: R; query lane: nodes per tile */
+    int waves_per_pair; /* row sweep: W; query lane: 0 */
     unsigned nprofiles;
     float ms;
     uint64_t cells;

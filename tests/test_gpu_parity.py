@@ -26,6 +26,13 @@ def scanner(dcp):
     s.close()
 
 
+@pytest.fixture(params=["rowsweep", "qlane"])
+def kern(request, dcp):
+    """Every parity test runs on both kernels: the row sweep (one wavefront group per pair) and
+    the query-lane throughput kernel (forced even for tiny batches)."""
+    return dcp.KERNEL_ROWSWEEP if request.param == "rowsweep" else dcp.KERNEL_QLANE
+
+
 def rand_seqs(rng, n, lo, hi):
     return [rng.integers(0, 4, int(rng.integers(lo, hi + 1)), dtype=np.uint8) for _ in range(n)]
 
@@ -68,7 +75,7 @@ def same_bits(a, b):
 
 
 @pytest.mark.parametrize("multi,h3", [(True, False), (False, False), (True, True)])
-def test_dp_bit_exact_small(dcp, oracle32, scanner, multi, h3):
+def test_dp_bit_exact_small(dcp, oracle32, scanner, multi, h3, kern):
     rng = np.random.default_rng(1)
     specs = [(1, 2, ENTRY_DIST_UNIFORM, 0.1), (2, 2, ENTRY_DIST_OCCUPANCY, 0.01),
              (3, 7, ENTRY_DIST_OCCUPANCY, 0.01), (4, 63, ENTRY_DIST_OCCUPANCY, 0.01),
@@ -81,7 +88,7 @@ def test_dp_bit_exact_small(dcp, oracle32, scanner, multi, h3):
     seqs += [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 14, 15, 16, 17, 33, 64, 100, 301)]
     scanner.upload_db(profiles, expand_on_host=True)
     scanner.upload_seqs(seqs)
-    scanner.scan(multi, h3, 10.0)
+    scanner.scan(multi, h3, 10.0, kernel=kern)
     gn, ga = scanner.scores()
     on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, h3, True)
     assert same_bits(gn, on)
@@ -101,7 +108,7 @@ def test_device_expansion_matches_host(dcp, scanner):
         np.testing.assert_allclose(em, host, rtol=3e-7, atol=1e-6)
 
 
-def test_end_to_end_vs_oracle(dcp, oracle32, scanner):
+def test_end_to_end_vs_oracle(dcp, oracle32, scanner, kern):
     """Device-expanded tables, oracle's independent float32 chain, incl. generic graph Viterbi."""
     rng = np.random.default_rng(2)
     specs = [(31, 2, ENTRY_DIST_UNIFORM, 0.1), (32, 17, ENTRY_DIST_OCCUPANCY, 0.01),
@@ -111,7 +118,7 @@ def test_end_to_end_vs_oracle(dcp, oracle32, scanner):
     seqs = rand_seqs(rng, 12, 20, 400)
     scanner.upload_db(profiles)
     scanner.upload_seqs(seqs)
-    scanner.scan(True, False, 10.0)
+    scanner.scan(True, False, 10.0, kernel=kern)
     gn, ga = scanner.scores()
     oprofs = [oracle32.sample(s, M, e, eps) for s, M, e, eps in specs]
     hits, on, oa = oracle32.scan(oprofs, [bytes(s) for s in seqs], True, False, 10.0, nthreads=4, mode=1)
@@ -125,7 +132,7 @@ def test_end_to_end_vs_oracle(dcp, oracle32, scanner):
             assert abs(oprofs[p].viterbi(0, bytes(seqs[q]), want_path=False)[1] - gn[q, p]) <= REL * abs(gn[q, p])
 
 
-def test_reference_goldens_through_the_gpu(dcp, scanner):
+def test_reference_goldens_through_the_gpu(dcp, scanner, kern):
     """test/protein_profile.c:41,65,157 on the HIP path, at the reference's float32 tolerance."""
     seq = "ATGAAACGCATTAGCACCACCATTACCACCAC"
     for entry, gold in ((ENTRY_DIST_UNIFORM, -55.59428153448), (ENTRY_DIST_OCCUPANCY, -54.35543421312)):
@@ -133,7 +140,7 @@ def test_reference_goldens_through_the_gpu(dcp, scanner):
         for host in (True, False):
             scanner.upload_db([prof], expand_on_host=host)
             scanner.upload_seqs([seq])
-            scanner.scan(True, False, 10.0)
+            scanner.scan(True, False, 10.0, kernel=kern)
             nl, al = scanner.scores()
             assert abs(nl[0, 0] - (-48.9272687711)) <= REL * 48.93
             assert abs(al[0, 0] - gold) <= REL * abs(gold)
@@ -190,7 +197,7 @@ def planted_query(rng, oprof, prof_len, flank=30):
                            rng.integers(0, 4, flank, dtype=np.uint8)])
 
 
-def test_hits_and_lrt_filter(dcp, oracle32, scanner):
+def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
     """Planted hits pass the LRT filter exactly where the oracle says (scan_thread.c:121-123)."""
     rng = np.random.default_rng(3)
     sizes = [40, 53, 66, 79, 92, 105]
@@ -208,7 +215,7 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner):
     scanner.upload_db(profiles, expand_on_host=True)
     scanner.upload_seqs(seqs)
     for multi in (True, False):
-        scanner.scan(multi, False, 10.0)
+        scanner.scan(multi, False, 10.0, kernel=kern)
         gn, ga = scanner.scores()
         on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
         assert same_bits(gn, on) and same_bits(ga, oa)
@@ -227,14 +234,14 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner):
         np.testing.assert_allclose(ga, ea, rtol=REL)
         np.testing.assert_allclose(gn, en, rtol=REL)
     # the two-domain query scores higher with multi-hit than without
-    scanner.scan(True, False, 10.0)
+    scanner.scan(True, False, 10.0, kernel=kern)
     a_multi = scanner.scores()[1][9, 3]
-    scanner.scan(False, False, 10.0)
+    scanner.scan(False, False, 10.0, kernel=kern)
     a_uni = scanner.scores()[1][9, 3]
     assert a_multi > a_uni
 
 
-def test_scan_is_idempotent_and_order_free(dcp, scanner):
+def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
     """Size-independent properties: same scores on re-scan, under profile permutation and
     when the batch is split (pairs are independent)."""
     rng = np.random.default_rng(4)
@@ -243,18 +250,18 @@ def test_scan_is_idempotent_and_order_free(dcp, scanner):
     seqs = rand_seqs(rng, 40, 30, 250)
     scanner.upload_db(profiles)
     scanner.upload_seqs(seqs)
-    scanner.scan()
+    scanner.scan(kernel=kern)
     n1, a1 = scanner.scores()
-    scanner.scan()
+    scanner.scan(kernel=kern)
     n2, a2 = scanner.scores()
     assert same_bits(n1, n2) and same_bits(a1, a2)
     perm = rng.permutation(len(profiles))
     scanner.upload_db([profiles[i] for i in perm])
-    scanner.scan()
+    scanner.scan(kernel=kern)
     n3, a3 = scanner.scores()
     assert same_bits(n3, n1[:, perm]) and same_bits(a3, a1[:, perm])
     scanner.upload_seqs(seqs[10:25])
-    scanner.scan()
+    scanner.scan(kernel=kern)
     n4, a4 = scanner.scores()
     assert same_bits(n4, n1[10:25][:, perm]) and same_bits(a4, a1[10:25][:, perm])
 
@@ -271,7 +278,7 @@ def delete_heavy_params(rng, M):
 
 @pytest.mark.parametrize("sizes", [(257, 300, 384), (385, 512, 513), (700, 768, 1024),
                                    (1025, 1536, 2048), (2049, 3072, 4096)])
-def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes):
+def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes, kern):
     """Multi-wavefront kernels (core_size > 256), incl. the maximum core size 4096
     (PROTEIN_MODEL_CORE_SIZE_MAX, limits.h:11)."""
     rng = np.random.default_rng(sum(sizes))
@@ -279,7 +286,7 @@ def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes):
     seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 4, 5, 6, 23, 60)]
     scanner.upload_db(profiles, expand_on_host=True)
     scanner.upload_seqs(seqs)
-    scanner.scan(True, False, 10.0)
+    scanner.scan(True, False, 10.0, kernel=kern)
     gn, ga = scanner.scores()
     on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
     assert same_bits(gn, on)
@@ -287,7 +294,7 @@ def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes):
 
 
 @pytest.mark.parametrize("M", [40, 200, 256, 500, 1000, 2500])
-def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M):
+def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M, kern):
     rng = np.random.default_rng(M)
     cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
     prm = delete_heavy_params(rng, M)
@@ -311,7 +318,7 @@ def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M):
     scanner.upload_db([prof], expand_on_host=True)
     scanner.upload_seqs(seqs)
     for multi in (True, False):
-        scanner.scan(multi, False, 10.0)
+        scanner.scan(multi, False, 10.0, kernel=kern)
         gn, ga = scanner.scores()
         on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, [prof], seqs, multi, False, True)
         assert same_bits(gn, on)
