@@ -28,6 +28,16 @@ namespace
 {
 constexpr int NC = DCP_NCODES;
 
+// Read-only tables are accessed through the constant address space: the data
+// never changes during the kernel, and loads at wave-uniform addresses then
+// become scalar (SMEM) loads instead of per-lane VMEM loads -- the compiler
+// cannot prove that on its own because the kernel also stores to global memory.
+typedef float const __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat *as_const(float const *p)
+{
+    return (cfloat *)(unsigned long long)p;
+}
+
 __device__ __forceinline__ float ninf() { return -__builtin_inff(); }
 __device__ __forceinline__ float mx3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float mx5(float a, float b, float c, float d, float e)
@@ -62,7 +72,7 @@ struct SweepOut
 
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 template <int G, bool FIRST, bool LAST, int PH>
-__device__ __forceinline__ void ql_row(QState<G> &s, float const *__restrict__ tt,
+__device__ __forceinline__ void ql_row(QState<G> &s, cfloat *tt,
                                        float const *tabM, float const *tabI, float const *tabN,
                                        unsigned w, float *__restrict__ pB, float *__restrict__ pXm,
                                        float *__restrict__ pXd, float *__restrict__ pEm,
@@ -129,7 +139,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, float const *__restrict__ t
             constexpr int dummy = 0;
             (void)dummy;
             int const k = 4 * g + r;
-            float const *__restrict__ tk = tt + k * 8;
+            cfloat *tk = tt + k * 8;
             float const e0 = r == 0 ? e[0].x : r == 1 ? e[0].y : r == 2 ? e[0].z : e[0].w;
             float const e1 = r == 0 ? e[1].x : r == 1 ? e[1].y : r == 2 ? e[1].z : e[1].w;
             float const e2 = r == 0 ? e[2].x : r == 1 ? e[2].y : r == 2 ? e[2].z : e[2].w;
@@ -159,7 +169,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, float const *__restrict__ t
 
     if constexpr (!LAST)
     {
-        float const *__restrict__ tn = tt + KT * 8; // edges into the next tile's first node
+        cfloat *tn = tt + KT * 8; // edges into the next tile's first node
         *pXm = mx3(pm + tn[DCP_T_MM], pi + tn[DCP_T_IM], pd + tn[DCP_T_DM]);
         *pXd = fmaxf(pm + tn[DCP_T_MD], pd + tn[DCP_T_DD]);
         *pEm = E;
@@ -186,7 +196,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, float const *__restrict__ t
 
 // Sweep one tile over rows 1..L of this lane's query.
 template <int G, bool FIRST, bool LAST>
-__device__ __forceinline__ void ql_sweep(float const *__restrict__ tt, float const *tabM,
+__device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM,
                                          float const *tabI, float const *tabN,
                                          uint32_t const *__restrict__ words, unsigned L,
                                          unsigned Lwave, bool active, float *__restrict__ sc,
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
     {
         if (tid == 0) s_task = atomicAdd(a.task_counter, 1u);
         __syncthreads();
-        unsigned const task = s_task;
+        unsigned const task = __builtin_amdgcn_readfirstlane(s_task); // uniform: transitions via SMEM
         __syncthreads();
         if (task >= a.ntasks) break;
         // biggest profiles first (metas are sorted by ascending size)
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
                 }
                 __syncthreads();
                 if (Lwave == 0u) continue; // no lane of this wavefront has work
-                float const *__restrict__ tt = a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8;
+                cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
                 bool const first = t == 0, last = t + 1 == T;
                 if (first && last)
                     ql_sweep<G, true, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, xt, first_iter, dirty, o);
