@@ -80,7 +80,7 @@ struct dcp_gpu_ctx
     DevBuf<dcp_prof_meta> d_metas;
     DevBuf<float> d_emis_match, d_emis_insert, d_emis_null, d_trans8;
     // query-lane kernel layout (dcp_qlane.hip)
-    int ql_G = 3; // nodes per tile = 4 * G
+    int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
     std::vector<dcp_ql_prof> ql_metas; // same order as metas
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
@@ -501,7 +501,7 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
         uint32_t L = seq_off[q + 1] - seq_off[q];
         woff[q] = (uint32_t)nwords;
         len[q] = L;
-        nwords += L / 16 + 1; // +1: the look-ahead base of the last row stays in bounds
+        nwords += L / 16 + 3; // pad: the kernels look ahead by up to one word + two bases
         total += L;
         if (nwords > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
     }
@@ -718,7 +718,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
         unsigned const nblocks = (unsigned)std::min<uint64_t>(ntasks, 2ull * c->num_cus);
-        size_t const need = (size_t)nblocks * 4u * qa.lmax * 256u;
+        size_t const need = (size_t)nblocks * 4u * ((size_t)qa.lmax + 8u) * 256u; // planes of lmax+8 rows
         if (c->d_scratch.n < need) HIP_TRY(c, c->d_scratch.alloc(need));
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));

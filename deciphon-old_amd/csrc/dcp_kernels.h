@@ -79,7 +79,7 @@ struct dcp_qlane_args
     uint32_t const *seq_len;
     float const *xtrans;
     uint32_t const *qorder;   // [nseqs] query indices sorted by length
-    float *scratch;           // [nblocks][4 planes][lmax][256]
+    float *scratch;           // [nblocks][4 planes][lmax + 8][256]
     unsigned *task_counter;
     float *out_null;
     float *out_alt;

@@ -42,7 +42,7 @@ __device__ __forceinline__ float ninf() { return -__builtin_inff(); }
 __device__ __forceinline__ float mx3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float mx5(float a, float b, float c, float d, float e)
 {
-    return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), e);
+    return mx3(mx3(a, b, c), d, e); // two v_max3_f32
 }
 
 __device__ __forceinline__ unsigned code_of(unsigned w, int l)
@@ -70,42 +70,129 @@ struct SweepOut
     float E, C, Rn;
 };
 
+// The tile's transitions, loaded once per sweep.  They are wave-uniform, so the
+// compiler keeps them in SGPRs (free second operand of v_add_f32).  Re-loading
+// them inside the row loop would cost nothing on the VALU, but SMEM shares the
+// lgkmcnt counter with LDS and returns out of order: every use would force
+// s_waitcnt lgkmcnt(0) and drain the LDS gathers in flight.
+template <int G> struct TileTrans
+{
+    float ent[4 * G], mi[4 * G], ii[4 * G];
+    float mm[4 * G + 1], im[4 * G + 1], dm[4 * G + 1], md[4 * G + 1], dd[4 * G + 1]; // [k]: edges INTO node k
+};
+
+template <int G> __device__ __forceinline__ void load_tile_trans(TileTrans<G> &t, cfloat *tt)
+{
+    constexpr int KT = 4 * G;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+    {
+        t.ent[k] = tt[k * 8 + DCP_T_ENTRY];
+        t.mi[k] = tt[k * 8 + DCP_T_MI];
+        t.ii[k] = tt[k * 8 + DCP_T_II];
+    }
+#pragma unroll
+    for (int k = 1; k <= KT; ++k)
+    {
+        t.mm[k] = tt[k * 8 + DCP_T_MM];
+        t.im[k] = tt[k * 8 + DCP_T_IM];
+        t.dm[k] = tt[k * 8 + DCP_T_DM];
+        t.md[k] = tt[k * 8 + DCP_T_MD];
+        t.dd[k] = tt[k * 8 + DCP_T_DD];
+    }
+    t.mm[0] = t.im[0] = t.dm[0] = t.md[0] = t.dd[0] = 0.0f; // unused: node 0 takes Xm / Xd
+}
+
+// What a row needs from memory, fetched one row ahead (software pipeline):
+// gather group 0 of the match tables, the insert / background emissions and the
+// previous tile's boundary values.  Groups 1.. are fetched at the top of the row
+// and land while group 0 is being computed.
+struct RowIn
+{
+    float4 e0[5];
+    float eI[5], eN[5];
+};
+
+// Boundary values of the previous tile (and the B in use), fetched FIVE rows
+// ahead into a register ring indexed by j % 5: a row's compute time (~0.6 us) is
+// shorter than loaded-HBM latency, and with two waves per SIMD a late load stalls
+// the SIMD.
+struct Ring
+{
+    float B[5], Xm[5], Xd[5], Em[5];
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, float const *pXm,
+                                           float const *pXd, float const *pEm, unsigned off,
+                                           bool first_iter)
+{
+    if constexpr (!FIRST)
+    {
+        r.Xm[slot] = pXm[off];
+        r.Xd[slot] = pXd[off];
+        r.Em[slot] = pEm[off];
+    }
+    if (!FIRST || !first_iter) r.B[slot] = pB[off];
+}
+
+template <int G, bool FIRST, bool LAST>
+__device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float const *tabI,
+                                         float const *tabN, unsigned w)
+{
+#pragma unroll
+    for (int l = 0; l < 5; ++l)
+    {
+        unsigned const c = code_of(w, l + 1);
+        in.e0[l] = *reinterpret_cast<float4 const *>(tabM + (size_t)c * 4);
+        in.eI[l] = tabI[c];
+        if constexpr (FIRST || LAST) in.eN[l] = tabN[c];
+    }
+}
+
+template <int R> __device__ __forceinline__ float comp(float4 const &v)
+{
+    return R == 0 ? v.x : R == 1 ? v.y : R == 2 ? v.z : v.w;
+}
+
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
+// `in` holds this row's prefetched inputs and is refilled for row j+1 (window
+// wn) as soon as group 0 has consumed it.
 template <int G, bool FIRST, bool LAST, int PH>
-__device__ __forceinline__ void ql_row(QState<G> &s, cfloat *tt,
-                                       float const *tabM, float const *tabI, float const *tabN,
-                                       unsigned w, float *__restrict__ pB, float *__restrict__ pXm,
-                                       float *__restrict__ pXd, float *__restrict__ pEm,
-                                       LaneXt const &xt, bool first_iter, bool &dirty, SweepOut &o)
+__device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
+                                       float const *tabI, float const *tabN, unsigned w,
+                                       unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
+                                       float *pXd, float *pEm, unsigned off, LaneXt const &xt,
+                                       bool first_iter, bool live, bool at_end, bool &dirty,
+                                       SweepOut &o)
 {
     constexpr int KT = 4 * G;
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;
     float const ni = ninf();
 
-    unsigned c[5];
+    // gather groups 1.. of this row now; they land while group 0 computes
+    float4 e[G > 1 ? G - 1 : 1][5];
 #pragma unroll
-    for (int l = 0; l < 5; ++l)
-        c[l] = code_of(w, l + 1);
+    for (int g = 1; g < G; ++g)
+#pragma unroll
+        for (int l = 0; l < 5; ++l)
+            e[g - 1][l] = *reinterpret_cast<float4 const *>(tabM + ((size_t)g * NC + code_of(w, l + 1)) * 4);
 
-    // boundary of the previous tile and the B this iteration runs with
-    float Xm = ni, Xd = ni, E = ni, Bj;
+    float Xm = ni, Xd = ni, E = ni, Bj = ring.B[PH];
     if constexpr (!FIRST)
     {
-        Xm = *pXm;
-        Xd = *pXd;
-        E = *pEm;
+        Xm = ring.Xm[PH];
+        Xd = ring.Xd[PH];
+        E = ring.Em[PH];
     }
-    if (!FIRST || !first_iter) Bj = *pB;
-
+    // slot PH is consumed: fetch row j+5 into it
+    ring_fetch<FIRST>(ring, PH, pB, pXm, pXd, pEm, off + 5u * 256u, first_iter);
     float eI[5], eN[5];
 #pragma unroll
     for (int l = 0; l < 5; ++l)
-        eI[l] = tabI[c[l]];
-    if constexpr (FIRST || LAST)
     {
-#pragma unroll
-        for (int l = 0; l < 5; ++l)
-            eN[l] = tabN[c[l]];
+        eI[l] = in.eI[l];
+        eN[l] = in.eN[l];
     }
 
     if constexpr (FIRST)
@@ -119,60 +206,60 @@ __device__ __forceinline__ void ql_row(QState<G> &s, cfloat *tt,
                                  s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
             s.PN[PH] = N + xt.NN;
             s.PR[PH] = Rn + xt.RR;
-            o.Rn = Rn;
+            o.Rn = at_end ? Rn : o.Rn;
             Bj = N + xt.NB;
-            *pB = Bj;
+            pB[off] = Bj;
         }
     }
 
     float pm = ni, pi = ni, pd = ni; // node k-1 of this row
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-    {
-        float4 e[5];
-#pragma unroll
-        for (int l = 0; l < 5; ++l)
-            e[l] = *reinterpret_cast<float4 const *>(tabM + ((size_t)g * NC + c[l]) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+    auto node = [&](int k, float e0, float e1, float e2, float e3, float e4) {
+        float const m = mx5(s.P[s1][k] + e0, s.P[s2][k] + e1, s.P[s3][k] + e2, s.P[s4][k] + e3,
+                            s.P[s5][k] + e4);
+        float const iv = mx5(s.Q[s1][k] + eI[0], s.Q[s2][k] + eI[1], s.Q[s3][k] + eI[2],
+                             s.Q[s4][k] + eI[3], s.Q[s5][k] + eI[4]);
+        float d, pin;
+        if (k == 0)
         {
-            constexpr int dummy = 0;
-            (void)dummy;
-            int const k = 4 * g + r;
-            cfloat *tk = tt + k * 8;
-            float const e0 = r == 0 ? e[0].x : r == 1 ? e[0].y : r == 2 ? e[0].z : e[0].w;
-            float const e1 = r == 0 ? e[1].x : r == 1 ? e[1].y : r == 2 ? e[1].z : e[1].w;
-            float const e2 = r == 0 ? e[2].x : r == 1 ? e[2].y : r == 2 ? e[2].z : e[2].w;
-            float const e3 = r == 0 ? e[3].x : r == 1 ? e[3].y : r == 2 ? e[3].z : e[3].w;
-            float const e4 = r == 0 ? e[4].x : r == 1 ? e[4].y : r == 2 ? e[4].z : e[4].w;
-            float const m = mx5(s.P[s1][k] + e0, s.P[s2][k] + e1, s.P[s3][k] + e2, s.P[s4][k] + e3,
-                                s.P[s5][k] + e4);
-            float const in = mx5(s.Q[s1][k] + eI[0], s.Q[s2][k] + eI[1], s.Q[s3][k] + eI[2],
-                                 s.Q[s4][k] + eI[3], s.Q[s5][k] + eI[4]);
-            float d, pin;
-            if (k == 0)
-            {
-                d = Xd;
-                pin = Xm;
-            }
-            else
-            {
-                d = fmaxf(pm + tk[DCP_T_MD], pd + tk[DCP_T_DD]);
-                pin = mx3(pm + tk[DCP_T_MM], pi + tk[DCP_T_IM], pd + tk[DCP_T_DM]);
-            }
-            E = mx3(E, m, d);
-            s.P[PH][k] = fmaxf(Bj + tk[DCP_T_ENTRY], pin);
-            s.Q[PH][k] = fmaxf(m + tk[DCP_T_MI], in + tk[DCP_T_II]);
-            pm = m, pi = in, pd = d;
+            d = Xd;
+            pin = Xm;
         }
+        else
+        {
+            d = fmaxf(pm + tr.md[k], pd + tr.dd[k]);
+            pin = mx3(pm + tr.mm[k], pi + tr.im[k], pd + tr.dm[k]);
+        }
+        E = mx3(E, m, d);
+        s.P[PH][k] = fmaxf(Bj + tr.ent[k], pin);
+        s.Q[PH][k] = fmaxf(m + tr.mi[k], iv + tr.ii[k]);
+        pm = m, pi = iv, pd = d;
+    };
+
+    // group 0 from the prefetched registers
+    node(0, in.e0[0].x, in.e0[1].x, in.e0[2].x, in.e0[3].x, in.e0[4].x);
+    node(1, in.e0[0].y, in.e0[1].y, in.e0[2].y, in.e0[3].y, in.e0[4].y);
+    node(2, in.e0[0].z, in.e0[1].z, in.e0[2].z, in.e0[3].z, in.e0[4].z);
+    node(3, in.e0[0].w, in.e0[1].w, in.e0[2].w, in.e0[3].w, in.e0[4].w);
+
+    // `in` is consumed: refill it for row j+1 while the other groups compute
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, wn);
+
+#pragma unroll
+    for (int g = 1; g < G; ++g)
+    {
+        float4 const *eg = e[g - 1];
+        node(4 * g + 0, eg[0].x, eg[1].x, eg[2].x, eg[3].x, eg[4].x);
+        node(4 * g + 1, eg[0].y, eg[1].y, eg[2].y, eg[3].y, eg[4].y);
+        node(4 * g + 2, eg[0].z, eg[1].z, eg[2].z, eg[3].z, eg[4].z);
+        node(4 * g + 3, eg[0].w, eg[1].w, eg[2].w, eg[3].w, eg[4].w);
     }
 
     if constexpr (!LAST)
     {
-        cfloat *tn = tt + KT * 8; // edges into the next tile's first node
-        *pXm = mx3(pm + tn[DCP_T_MM], pi + tn[DCP_T_IM], pd + tn[DCP_T_DM]);
-        *pXd = fmaxf(pm + tn[DCP_T_MD], pd + tn[DCP_T_DD]);
-        *pEm = E;
+        // edges into the next tile's first node
+        pXm[off] = mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]);
+        pXd[off] = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
+        pEm[off] = E;
     }
     else
     {
@@ -182,29 +269,31 @@ __device__ __forceinline__ void ql_row(QState<G> &s, cfloat *tt,
                             s.PC[s5] + eN[4]);
         // did E(j) -> B(j) or J(j) -> B(j) beat the B(j) this sweep ran with?
         float const B1 = fmaxf(E + xt.EB, J + xt.JB);
-        if (B1 > Bj)
+        if (live && B1 > Bj)
         {
             dirty = true;
-            *pB = B1;
+            pB[off] = B1;
         }
         s.PJ[PH] = fmaxf(E + xt.EJ, J + xt.JJ);
         s.PC[PH] = fmaxf(E + xt.EC, C + xt.CC);
-        o.E = E;
-        o.C = C;
+        o.E = at_end ? E : o.E;
+        o.C = at_end ? C : o.C;
     }
 }
 
-// Sweep one tile over rows 1..L of this lane's query.
+// Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
+// addressed as (wave-uniform plane base) + (32-bit lane/row offset).
 template <int G, bool FIRST, bool LAST>
-__device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM,
-                                         float const *tabI, float const *tabN,
-                                         uint32_t const *__restrict__ words, unsigned L,
-                                         unsigned Lwave, bool active, float *__restrict__ sc,
-                                         size_t plane, LaneXt const &xt, bool first_iter,
-                                         bool &dirty, SweepOut &o)
+__device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float const *tabI,
+                                         float const *tabN, uint32_t const *__restrict__ words,
+                                         unsigned L, unsigned Lwave, bool active, float *sc,
+                                         size_t plane, unsigned tid, LaneXt const &xt,
+                                         bool first_iter, bool &dirty, SweepOut &o)
 {
     constexpr int KT = 4 * G;
     float const ni = ninf();
+    TileTrans<G> tr;
+    load_tile_trans<G>(tr, tt);
     QState<G> s;
 #pragma unroll
     for (int h = 0; h < 5; ++h)
@@ -219,25 +308,58 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM,
         float const B0 = 0.0f + xt.SB;
 #pragma unroll
         for (int k = 0; k < KT; ++k)
-            s.P[0][k] = B0 + tt[k * 8 + DCP_T_ENTRY];
+            s.P[0][k] = B0 + tr.ent[k];
         s.PN[0] = 0.0f + xt.SN;
         s.PR[0] = 0.0f;
     }
     float *pB = sc, *pXm = sc + plane, *pXd = sc + 2 * plane, *pEm = sc + 3 * plane;
-    unsigned w = 0, cur = 0, j = 1;
+    unsigned off = tid; // (j - 1) * 256 + tid
+
+    // sequence window: w = row j, wn = row j+1 (the word past the last base is padding)
+    // Every lane of the wavefront executes every row up to Lwave -- no per-lane
+    // branch around the row body: values loaded inside a divergent `if` would reach
+    // the next row through phi copies, and a copy needs its load complete, which
+    // drains every prefetch at the end of each row.  A lane past its own length
+    // (or without a query) computes garbage into its own scratch column and its
+    // own registers; its results were captured at row L (`at_end`), `live` guards
+    // the only externally visible effects.
+    unsigned const wlast = L / 16u + 2u; // last word of this lane's sequence (incl. padding)
+    unsigned cur = words[0], nxt = words[1], j = 1;
+    unsigned w = cur & 3u;
+    unsigned wn = ((w << 2) | ((cur >> 2) & 3u)) & 1023u;
+    RowIn in;
+    Ring ring;
+#pragma unroll
+    for (int l = 0; l < 5; ++l)
+    {
+        in.e0[l] = float4{ni, ni, ni, ni}, in.eI[l] = ni, in.eN[l] = ni;
+        ring.B[l] = ring.Xm[l] = ring.Xd[l] = ring.Em[l] = ni;
+    }
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, w);
+#pragma unroll
+    for (int r = 0; r < 5; ++r) // rows 1..5 -> slots 1,2,3,4,0
+        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * 256u, first_iter);
 
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
-        if (active && j <= L)                                                              \
+        ql_row<G, FIRST, LAST, PH>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm, pXd, \
+                                   pEm, off, xt, first_iter, active && j <= L,             \
+                                   active && j == L, dirty, o);                            \
+        /* advance the window: base of row j+2 sits at position j+1; sequence words */     \
+        /* are fetched one word (16 rows) ahead, clamped to the lane's own sequence */     \
+        unsigned const pos = j + 1u;                                                       \
+        if ((pos & 15u) == 0u)                                                             \
         {                                                                                  \
-            unsigned const pos = j - 1u;                                                   \
-            if ((pos & 15u) == 0u) cur = words[pos >> 4];                                  \
-            w = ((w << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & 1023u;                   \
-            ql_row<G, FIRST, LAST, PH>(s, tt, tabM, tabI, tabN, w, pB, pXm, pXd, pEm, xt,  \
-                                       first_iter, dirty, o);                              \
+            cur = nxt;                                                                     \
+            nxt = words[min((pos >> 4) + 1u, wlast)];                                      \
         }                                                                                  \
-        pB += 256, pXm += 256, pXd += 256, pEm += 256;                                     \
+        w = wn;                                                                            \
+        wn = ((wn << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & 1023u;                     \
+        off += 256u;                                                                       \
         ++j;                                                                               \
+        /* keep the scheduler from pulling the next row's loads up here: the only   */     \
+        /* cross-row traffic is the explicit prefetch above (register budget)       */     \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
     }
     while (j + 4 <= Lwave)
     {
@@ -272,8 +394,9 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
     __shared__ unsigned s_task;
     float *tabM = lds, *tabI = lds + TAB_FLOATS, *tabN = tabI + NC;
     unsigned const tid = threadIdx.x;
-    size_t const plane = (size_t)a.lmax * 256u;
-    float *const sc = a.scratch + (size_t)blockIdx.x * 4u * plane + tid;
+    // +8 rows: the software pipeline reads row j+5's boundary while computing row j
+    size_t const plane = ((size_t)a.lmax + 8u) * 256u;
+    float *const sc = a.scratch + (size_t)blockIdx.x * 4u * plane; // wave-uniform base
 
     for (;;)
     {
@@ -333,13 +456,13 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
                 cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
                 bool const first = t == 0, last = t + 1 == T;
                 if (first && last)
-                    ql_sweep<G, true, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, xt, first_iter, dirty, o);
+                    ql_sweep<G, true, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
                 else if (first)
-                    ql_sweep<G, true, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, xt, first_iter, dirty, o);
+                    ql_sweep<G, true, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
                 else if (last)
-                    ql_sweep<G, false, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, xt, first_iter, dirty, o);
+                    ql_sweep<G, false, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
                 else
-                    ql_sweep<G, false, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, xt, first_iter, dirty, o);
+                    ql_sweep<G, false, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
             }
             first_iter = false;
             if (!__syncthreads_or(dirty ? 1 : 0)) break;
