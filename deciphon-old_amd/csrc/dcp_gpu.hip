@@ -174,8 +174,7 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
     {
         hipDeviceProp_t prop;
         c->num_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? (unsigned)prop.multiProcessorCount : 256u;
-        char const *g = getenv("DCP_QLANE_G");
-        if (g && (atoi(g) == 2 || atoi(g) == 3)) c->ql_G = atoi(g);
+        c->ql_G = (int)dcp_qlane_tile_nodes() / 4;
     }
     bool ok = true;
     for (int k = 0; k < kNumClasses; ++k)
@@ -713,18 +712,25 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.nseqs = nq;
         qa.q_base = q_begin;
         qa.lmax = c->qorder_lmax;
-        qa.nqblocks = (nq + 255u) / 256u;
+        unsigned const NT = dcp_qlane_block_size();
+        qa.nqblocks = (nq + NT - 1u) / NT;
+        qa.dbg_wmask = 1023u;
+        qa.dbg_rowstep = NT;
+        if (char const *d = getenv("DCP_QLANE_DEBUG"))
+        {
+            if (atoi(d) & 1) qa.dbg_wmask = 0u;
+            if (atoi(d) & 2) qa.dbg_rowstep = 0u;
+        }
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
         unsigned const nblocks = (unsigned)std::min<uint64_t>(ntasks, 2ull * c->num_cus);
-        size_t const need = (size_t)nblocks * 4u * ((size_t)qa.lmax + 8u) * 256u; // planes of lmax+8 rows
+        size_t const need = (size_t)nblocks * 4u * ((size_t)qa.lmax + 8u) * NT; // planes of lmax+8 rows
         if (c->d_scratch.n < need) HIP_TRY(c, c->d_scratch.alloc(need));
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-        if (dcp_launch_qlane(c->ql_G, &qa, nblocks, c->stream))
-            return c->fail(DCP_EFAIL, "no query-lane kernel for G=%d", c->ql_G);
+        if (dcp_launch_qlane(&qa, nblocks, c->stream)) return c->fail(DCP_EFAIL, "query-lane launch failed");
         c->last_launches = 1;
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));

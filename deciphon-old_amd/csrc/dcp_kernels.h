@@ -79,7 +79,7 @@ struct dcp_qlane_args
     uint32_t const *seq_len;
     float const *xtrans;
     uint32_t const *qorder;   // [nseqs] query indices sorted by length
-    float *scratch;           // [nblocks][4 planes][lmax + 8][256]
+    float *scratch;           // [nblocks][4 planes][lmax + 8][queries per block]
     unsigned *task_counter;
     float *out_null;
     float *out_alt;
@@ -93,7 +93,12 @@ struct dcp_qlane_args
     unsigned q_base;
     unsigned lmax;     // longest resident sequence of this scan
     unsigned ntasks;   // nprof * nqblocks
-    unsigned nqblocks; // ceil(nseqs / 256)
+    unsigned nqblocks; // ceil(nseqs / queries per block)
+    // timing diagnostics (DCP_QLANE_DEBUG; results are wrong when set): window mask 1023 ->
+    // 0 makes every lane gather table row 0 (no LDS bank conflicts); row step 256 -> 0
+    // collapses the scratch planes to one row (no HBM traffic)
+    unsigned dbg_wmask;
+    unsigned dbg_rowstep;
 };
 
 struct dcp_expand_args
@@ -111,7 +116,9 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
-int dcp_launch_qlane(int G, dcp_qlane_args const *a, unsigned nblocks, void *stream);
+int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream);
+unsigned dcp_qlane_block_size(void);
+unsigned dcp_qlane_tile_nodes(void);
 #ifdef __cplusplus
 }
 #endif

@@ -158,7 +158,7 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, int PH>
+template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float const *tabI, float const *tabN, unsigned w,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
@@ -185,8 +185,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         Xd = ring.Xd[PH];
         E = ring.Em[PH];
     }
-    // slot PH is consumed: fetch row j+5 into it
-    ring_fetch<FIRST>(ring, PH, pB, pXm, pXd, pEm, off + 5u * 256u, first_iter);
+    // fetch row j+D into its slot (slot PH itself when D == 5: it is consumed above)
+    ring_fetch<FIRST>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT), first_iter);
     float eI[5], eN[5];
 #pragma unroll
     for (int l = 0; l < 5; ++l)
@@ -283,12 +283,13 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST>
+template <int G, bool FIRST, bool LAST, int NT, int D>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float const *tabI,
                                          float const *tabN, uint32_t const *__restrict__ words,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt,
-                                         bool first_iter, bool &dirty, SweepOut &o)
+                                         bool first_iter, bool &dirty, SweepOut &o,
+                                         unsigned wmask, unsigned rowstep)
 {
     constexpr int KT = 4 * G;
     float const ni = ninf();
@@ -325,8 +326,8 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
     // the only externally visible effects.
     unsigned const wlast = L / 16u + 2u; // last word of this lane's sequence (incl. padding)
     unsigned cur = words[0], nxt = words[1], j = 1;
-    unsigned w = cur & 3u;
-    unsigned wn = ((w << 2) | ((cur >> 2) & 3u)) & 1023u;
+    unsigned w = cur & 3u & wmask;
+    unsigned wn = ((w << 2) | ((cur >> 2) & 3u)) & wmask;
     RowIn in;
     Ring ring;
 #pragma unroll
@@ -337,12 +338,12 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
     }
     ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, w);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) // rows 1..5 -> slots 1,2,3,4,0
-        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * 256u, first_iter);
+    for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
+        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT), first_iter);
 
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
-        ql_row<G, FIRST, LAST, PH>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm, pXd, \
+        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm, pXd, \
                                    pEm, off, xt, first_iter, active && j <= L,             \
                                    active && j == L, dirty, o);                            \
         /* advance the window: base of row j+2 sits at position j+1; sequence words */     \
@@ -354,8 +355,8 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
             nxt = words[min((pos >> 4) + 1u, wlast)];                                      \
         }                                                                                  \
         w = wn;                                                                            \
-        wn = ((wn << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & 1023u;                     \
-        off += 256u;                                                                       \
+        wn = ((wn << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & wmask;                     \
+        off += rowstep;                                                                     \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
         /* cross-row traffic is the explicit prefetch above (register budget)       */     \
@@ -385,8 +386,8 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 
 } // namespace
 
-template <int G>
-__global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
+template <int G, int NT, int D>
+__global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_args a)
 {
     constexpr int KT = 4 * G;
     constexpr int TAB_FLOATS = G * NC * 4;
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
     __shared__ unsigned s_task;
     float *tabM = lds, *tabI = lds + TAB_FLOATS, *tabN = tabI + NC;
     unsigned const tid = threadIdx.x;
-    // +8 rows: the software pipeline reads row j+5's boundary while computing row j
-    size_t const plane = ((size_t)a.lmax + 8u) * 256u;
+    // +8 rows: the software pipeline reads row j+D's boundary while computing row j
+    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * 4u * plane; // wave-uniform base
 
     for (;;)
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
         dcp_ql_prof const pm = a.profs[slot];
         unsigned const T = pm.ntiles;
 
-        unsigned const qi = qb * 256u + tid;
+        unsigned const qi = qb * (unsigned)NT + tid;
         bool const has = qi < a.nseqs;
         unsigned const q = has ? a.qorder[qi] : 0u;
         unsigned const L = has ? a.seq_len[q] : 0u;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
         {
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
-            for (unsigned i = tid; i < (unsigned)NC; i += 256u)
+            for (unsigned i = tid; i < (unsigned)NC; i += (unsigned)NT)
                 tabI[i] = gi[i], tabN[i] = gn[i];
         }
 
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
                     float4 const *__restrict__ src = reinterpret_cast<float4 const *>(
                         a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
                     float4 *dst = reinterpret_cast<float4 *>(tabM);
-                    for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += 256u)
+                    for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
                         dst[i] = src[i];
                 }
                 __syncthreads();
@@ -456,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
                 cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
                 bool const first = t == 0, last = t + 1 == T;
                 if (first && last)
-                    ql_sweep<G, true, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
+                    ql_sweep<G, true, true, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
                 else if (first)
-                    ql_sweep<G, true, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
+                    ql_sweep<G, true, false, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
                 else if (last)
-                    ql_sweep<G, false, true>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
+                    ql_sweep<G, false, true, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
                 else
-                    ql_sweep<G, false, false>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o);
+                    ql_sweep<G, false, false, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
             }
             first_iter = false;
             if (!__syncthreads_or(dirty ? 1 : 0)) break;
@@ -486,18 +487,21 @@ __global__ __launch_bounds__(256, 2) void viterbi_qlane_kernel(dcp_qlane_args a)
     }
 }
 
-template <int G> static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
+template <int G, int NT, int D>
+static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 {
-    hipLaunchKernelGGL((viterbi_qlane_kernel<G>), dim3(nblocks), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((viterbi_qlane_kernel<G, NT, D>), dim3(nblocks), dim3(NT), 0, s, *a);
 }
 
-extern "C" int dcp_launch_qlane(int G, dcp_qlane_args const *a, unsigned nblocks, void *stream)
+// One configuration is built: KT = 8 nodes per tile (G = 2: the tile's transitions fit in
+// SGPRs), 256 queries per block at 2 wavefronts per SIMD, boundary ring 5 rows deep.
+// Measured alternatives: KT = 12 spills at the 256-VGPR cap; 384-thread
+// blocks at 3 wavefronts per SIMD (168 VGPRs) spill ~840 registers and run 3x slower.
+extern "C" unsigned dcp_qlane_block_size(void) { return 256u; }
+extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
+
+extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    hipStream_t s = (hipStream_t)stream;
-    switch (G)
-    {
-    case 2: launch_ql<2>(a, nblocks, s); return 0;
-    case 3: launch_ql<3>(a, nblocks, s); return 0;
-    default: return -1;
-    }
+    launch_ql<2, 256, 5>(a, nblocks, (hipStream_t)stream);
+    return 0;
 }
