@@ -495,7 +495,7 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 
 // One configuration is built: KT = 8 nodes per tile (G = 2: the tile's transitions fit in
 // SGPRs), 256 queries per block at 2 wavefronts per SIMD, boundary ring 5 rows deep.
-// Measured alternatives (DESIGN.md §4.4): KT = 12 spills at the 256-VGPR cap; 384-thread
+// Measured alternatives (DESIGN.md §4.2): KT = 12 spills at the 256-VGPR cap; 384-thread
 // blocks at 3 wavefronts per SIMD (168 VGPRs) spill ~840 registers and run 3x slower.
 extern "C" unsigned dcp_qlane_block_size(void) { return 256u; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
