@@ -55,6 +55,8 @@ ABI_SYMBOLS = [
     "dcp_gpu_sync", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
     "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
     "dcp_gpu_last_scan_launch_info", "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
+    "dcp_gpu_trace_paths", "dcp_state_name", "dcp_profile_decode", "dcp_gc_decode",
+    "dcp_prod_format_row", "dcp_prod_header",
 ]
 
 
@@ -89,6 +91,7 @@ class LaunchInfo(C.Structure):
                 ("ms", C.c_float), ("cells", C.c_uint64), ("algorithmic_bytes", C.c_uint64)]
 
 
+STEP_DTYPE = np.dtype([("state_id", np.uint16), ("seqlen", np.uint8), ("reserved", np.uint8)])
 HIT_DTYPE = np.dtype([("seq_idx", np.uint32), ("profile_idx", np.uint32),
                       ("null_loglik", np.float32), ("alt_loglik", np.float32)])
 
@@ -135,6 +138,13 @@ def _load():
         "dcp_gpu_scan_range": (I, [P, C.POINTER(ScanParams), U, U]),
         "dcp_gpu_set_hit_buffer": (I, [P, P, U, P]),
         "dcp_gpu_last_scan_launch_info": (I, [P, U, C.POINTER(LaunchInfo)]),
+        "dcp_gpu_trace_paths": (I, [P, P, U, I, I, P, U, P, P]),
+        "dcp_state_name": (U, [U, C.c_char_p]),
+        "dcp_profile_decode": (I, [P, P, U, U, P]),
+        "dcp_gc_decode": (C.c_char, [P]),
+        "dcp_prod_format_row": (C.c_long, [C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p,
+                                           C.c_double, C.c_double, C.c_char_p, C.c_char_p, P, P, U, P, U]),
+        "dcp_prod_header": (C.c_char_p, []),
         "dcp_gpu_scan_cells": (C.c_uint64, [P]),
         "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
     }
@@ -209,6 +219,32 @@ class ProteinProfile:
     def core_size(self):
         return lib.dcp_profile_core_size(self._h)
 
+    def decode(self, frag, state_id):
+        """protein_profile_decode (src/model/protein_profile.c:306-331): most likely codon of a
+        1..5-nt fragment emitted by `state_id`, as an ACGT string. RC_EINVAL for mute states."""
+        f = encode_seq(frag) if isinstance(frag, str) else np.ascontiguousarray(frag, np.uint8)
+        out = np.zeros(3, np.uint8)
+        rc = lib.dcp_profile_decode(self._h, f.ctypes.data, len(f), int(state_id), out.ctypes.data)
+        if rc:
+            raise DcpError(rc, "failed to decode sequence")
+        return "".join("ACGT"[b] for b in out)
+
+    def prod_row(self, seq, steps, scan_id=0, seq_id=0, alt_loglik=0.0, null_loglik=0.0,
+                 abc_name="dna", profile_typeid="protein", version="0.0.0", profile_name=None):
+        """One product TSV row as prod_fwrite + protein_match_write_func write it
+        (src/server/prod.c:153-181, src/server/protein_match.c:21-56)."""
+        s = encode_seq(seq) if isinstance(seq, str) else np.ascontiguousarray(seq, np.uint8)
+        st = np.ascontiguousarray(steps, STEP_DTYPE)
+        cap = 256 + 64 * (len(st) + 1) + 2 * len(s)
+        buf = C.create_string_buffer(cap)
+        n = lib.dcp_prod_format_row(buf, cap, scan_id, seq_id, (profile_name or self.accession).encode(),
+                                    abc_name.encode(), float(alt_loglik), float(null_loglik),
+                                    profile_typeid.encode(), version.encode(), self._h, s.ctypes.data,
+                                    len(s), st.ctypes.data, len(st))
+        if n < 0:
+            raise DcpError(RC_EFAIL, "failed to write prod")
+        return buf.raw[:n].decode()
+
     @property
     def accession(self):
         return lib.dcp_profile_accession(self._h).decode()
@@ -232,6 +268,22 @@ class ProteinProfile:
     @property
     def match_dist(self):
         return self._view(lib.dcp_profile_match_dist(self._h), (self.core_size, NDIST))
+
+
+def state_name(state_id):
+    """protein_state_name (src/model/protein_state.c:5-39)."""
+    b = C.create_string_buffer(8)
+    lib.dcp_state_name(int(state_id), b)
+    return b.value.decode()
+
+
+def gc_decode(codon):
+    """imm_gc_decode(1, codon): amino acid letter of an ACGT codon string."""
+    c = encode_seq(codon)
+    return lib.dcp_gc_decode(c.ctypes.data).decode()
+
+
+PROD_HEADER = lib.dcp_prod_header().decode()
 
 
 def frame_table_host(dist, epsilon):
@@ -345,6 +397,7 @@ class Scanner:
         cat = np.ascontiguousarray(cat, np.uint8)
         off = np.ascontiguousarray(off, np.uint32)
         self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
+        self._seq_lens = np.diff(off.astype(np.int64))
 
     def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
              sync=True, q_range=None, kernel=KERNEL_AUTO):
@@ -395,6 +448,20 @@ class Scanner:
         al = np.zeros_like(nl)
         self._check(lib.dcp_gpu_fetch_scores(self._c, nl.ctypes.data, al.ctypes.data))
         return nl, al
+
+    def trace_paths(self, hits, multi_hits=True, hmmer3_compat=False):
+        """Alt Viterbi paths of the given hit records, computed on the device: a list of
+        STEP_DTYPE arrays, plus the alt log-likelihoods the trace recomputed."""
+        h = np.ascontiguousarray(hits, HIT_DTYPE)
+        n = len(h)
+        off = np.zeros(n + 1, np.uint32)
+        alt = np.zeros(n, np.float32)
+        cap = int(sum(2 * int(self._seq_lens[q]) + 2 * self._profiles[p].core_size + 16
+                      for q, p in zip(h["seq_idx"], h["profile_idx"]))) if n else 0
+        steps = np.zeros(max(cap, 1), STEP_DTYPE)
+        self._check(lib.dcp_gpu_trace_paths(self._c, h.ctypes.data, n, int(multi_hits), int(hmmer3_compat),
+                                            steps.ctypes.data, cap, off.ctypes.data, alt.ctypes.data))
+        return [steps[off[i]:off[i + 1]].copy() for i in range(n)], alt
 
     def hits(self, cap=1 << 20):
         buf = np.zeros(cap, HIT_DTYPE)

@@ -78,6 +78,8 @@ struct dcp_gpu_ctx
     std::vector<unsigned> core_sizes;   // by pidx
     unsigned class_first[kNumClasses + 1] = {0};
     DevBuf<dcp_prof_meta> d_metas;
+    DevBuf<uint32_t> d_slot_of_pidx;
+    std::vector<uint32_t> slot_of_pidx;
     DevBuf<float> d_emis_match, d_emis_insert, d_emis_null, d_trans8;
     // query-lane kernel layout (dcp_qlane.hip)
     int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
@@ -263,6 +265,11 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         return c->fail(DCP_EINVAL, "DB too large for 32-bit row offsets");
 
     HIP_TRY(c, c->d_metas.alloc(nprofiles));
+    c->slot_of_pidx.assign(nprofiles, 0);
+    for (unsigned i = 0; i < nprofiles; ++i)
+        c->slot_of_pidx[c->metas[i].pidx] = i;
+    HIP_TRY(c, c->d_slot_of_pidx.alloc(nprofiles));
+    HIP_TRY(c, hipMemcpy(c->d_slot_of_pidx.p, c->slot_of_pidx.data(), nprofiles * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
     HIP_TRY(c, c->d_trans8.alloc(trans_floats));
     HIP_TRY(c, c->d_emis_insert.alloc((size_t)nprofiles * DCP_NCODES));
@@ -555,6 +562,32 @@ int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *c, char const *text, uint32_t const *s
 // ---------------------------------------------------------------------------
 // Scan
 // ---------------------------------------------------------------------------
+// protein_profile_setup once per sequence (length) instead of once per pair
+static int ensure_xtrans(dcp_gpu_ctx *c, int multi_hits, int hmmer3_compat)
+{
+    if (c->xt_multi == !!multi_hits && c->xt_h3 == !!hmmer3_compat) return DCP_OK;
+    std::vector<float> xt((size_t)c->nseqs * DCP_XSTRIDE, 0.0f);
+    std::map<uint32_t, std::vector<float>> by_len;
+    for (unsigned q = 0; q < c->nseqs; ++q)
+    {
+        auto it = by_len.find(c->seq_len[q]);
+        if (it == by_len.end())
+        {
+            std::vector<float> v(DCP_XSTRIDE, 0.0f);
+            int rc = dcp_xtrans(c->seq_len[q], multi_hits, hmmer3_compat, v.data());
+            if (rc) return c->fail(rc, "sequence cannot be empty");
+            it = by_len.emplace(c->seq_len[q], std::move(v)).first;
+        }
+        std::memcpy(&xt[(size_t)q * DCP_XSTRIDE], it->second.data(), sizeof(float) * DCP_XSTRIDE);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_xtrans.p, xt.data(), xt.size() * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->xt_multi = !!multi_hits;
+    c->xt_h3 = !!hmmer3_compat;
+    return DCP_OK;
+}
+
 int dcp_gpu_scan(dcp_gpu_ctx *c, struct dcp_scan_params const *prm)
 {
     if (!c) return DCP_EINVAL;
@@ -581,29 +614,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (q_begin >= q_end || q_end > c->nseqs) return c->fail(DCP_EINVAL, "bad sequence range");
     HIP_TRY(c, hipSetDevice(c->device));
 
-    // protein_profile_setup once per sequence instead of once per pair
-    if (c->xt_multi != !!prm->multi_hits || c->xt_h3 != !!prm->hmmer3_compat)
-    {
-        std::vector<float> xt((size_t)c->nseqs * DCP_XSTRIDE, 0.0f);
-        std::map<uint32_t, std::vector<float>> by_len;
-        for (unsigned q = 0; q < c->nseqs; ++q)
-        {
-            auto it = by_len.find(c->seq_len[q]);
-            if (it == by_len.end())
-            {
-                std::vector<float> v(DCP_XSTRIDE, 0.0f);
-                int rc = dcp_xtrans(c->seq_len[q], prm->multi_hits, prm->hmmer3_compat, v.data());
-                if (rc) return c->fail(rc, "sequence cannot be empty");
-                it = by_len.emplace(c->seq_len[q], std::move(v)).first;
-            }
-            std::memcpy(&xt[(size_t)q * DCP_XSTRIDE], it->second.data(), sizeof(float) * DCP_XSTRIDE);
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->d_xtrans.p, xt.data(), xt.size() * sizeof(float),
-                                  hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->xt_multi = !!prm->multi_hits;
-        c->xt_h3 = !!prm->hmmer3_compat;
-    }
+    if (int rc = ensure_xtrans(c, prm->multi_hits, prm->hmmer3_compat)) return rc;
 
     size_t const npairs = (size_t)c->nseqs * c->nprof;
     if (prm->keep_scores)
@@ -851,6 +862,120 @@ int dcp_gpu_fetch_hits(dcp_gpu_ctx *c, struct dcp_hit *hits, unsigned cap, unsig
     return DCP_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Hits -> alt paths (device traceback)
+// ---------------------------------------------------------------------------
+int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhits,
+                        int multi_hits, int hmmer3_compat, struct dcp_step *steps_out,
+                        unsigned cap_steps, uint32_t *step_off, float *alt_out)
+{
+    if (!c || !step_off || (nhits && !hits)) return DCP_EINVAL;
+    if (c->nprof == 0 || c->nseqs == 0) return c->fail(DCP_EINVAL, "no DB / sequences resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    step_off[0] = 0;
+    if (nhits == 0) return DCP_OK;
+    for (unsigned h = 0; h < nhits; ++h)
+        if (hits[h].seq_idx >= c->nseqs || hits[h].profile_idx >= c->nprof)
+            return c->fail(DCP_EINVAL, "hit %u is outside the resident batch / DB", h);
+    if (int rc = ensure_xtrans(c, multi_hits, hmmer3_compat)) return rc;
+
+    // per-hit work area and step capacity
+    std::vector<uint64_t> need(nhits);
+    std::vector<uint32_t> cap(nhits);
+    for (unsigned h = 0; h < nhits; ++h)
+    {
+        dcp_prof_meta const &m = c->metas[c->slot_of_pidx[hits[h].profile_idx]];
+        uint64_t const L = c->seq_len[hits[h].seq_idx];
+        need[h] = 3ull * (L + 1) * m.ldk + 5ull * (L + 1);
+        cap[h] = (uint32_t)(2 * L + 2ull * m.core_size + 16);
+    }
+    uint64_t const budget = 1ull << 29; // floats (2 GiB) of work area per launch
+    int rc = DCP_OK;
+    uint64_t total_steps = 0;
+    std::vector<dcp_step> host_steps;
+    for (unsigned h0 = 0; h0 < nhits;)
+    {
+        unsigned h1 = h0;
+        uint64_t work = 0, scap = 0;
+        while (h1 < nhits && (h1 == h0 || work + need[h1] <= budget))
+            work += need[h1], scap += cap[h1], ++h1;
+        unsigned const n = h1 - h0;
+        std::vector<uint64_t> woff(n);
+        std::vector<uint32_t> soff(n + 1, 0);
+        uint64_t acc = 0;
+        for (unsigned i = 0; i < n; ++i)
+        {
+            woff[i] = acc;
+            acc += need[h0 + i];
+            soff[i + 1] = soff[i] + cap[h0 + i];
+        }
+        DevBuf<float> d_work, d_alt;
+        DevBuf<uint64_t> d_woff;
+        DevBuf<uint32_t> d_soff, d_nsteps;
+        DevBuf<dcp_step> d_steps;
+        DevBuf<dcp_hit> d_hits;
+        HIP_TRY(c, d_work.alloc(work));
+        HIP_TRY(c, d_alt.alloc(n));
+        HIP_TRY(c, d_woff.alloc(n));
+        HIP_TRY(c, d_soff.alloc(n + 1));
+        HIP_TRY(c, d_nsteps.alloc(n));
+        HIP_TRY(c, d_steps.alloc(scap));
+        HIP_TRY(c, d_hits.alloc(n));
+        HIP_TRY(c, hipMemcpy(d_woff.p, woff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_soff.p, soff.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_hits.p, hits + h0, n * sizeof(dcp_hit), hipMemcpyHostToDevice));
+        dcp_trace_args ta{};
+        ta.profs = c->d_metas.p;
+        ta.slot_of_pidx = c->d_slot_of_pidx.p;
+        ta.emis_match = c->d_emis_match.p;
+        ta.emis_insert = c->d_emis_insert.p;
+        ta.emis_null = c->d_emis_null.p;
+        ta.trans8 = c->d_trans8.p;
+        ta.seq_words = c->d_seq_words.p;
+        ta.seq_woff = c->d_seq_woff.p;
+        ta.seq_len = c->d_seq_len.p;
+        ta.xtrans = c->d_xtrans.p;
+        ta.hits = d_hits.p;
+        ta.nhits = n;
+        ta.work = d_work.p;
+        ta.work_off = d_woff.p;
+        ta.steps = d_steps.p;
+        ta.step_off = d_soff.p;
+        ta.nsteps = d_nsteps.p;
+        ta.alt_out = d_alt.p;
+        dcp_launch_trace(&ta, n, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> ns(n);
+        std::vector<dcp_step> st(scap);
+        HIP_TRY(c, hipMemcpy(ns.data(), d_nsteps.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(st.data(), d_steps.p, scap * sizeof(dcp_step), hipMemcpyDeviceToHost));
+        if (alt_out) HIP_TRY(c, hipMemcpy(alt_out + h0, d_alt.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < n; ++i)
+        {
+            if (ns[i] == 0xffffffffu)
+            {
+                rc = c->fail(DCP_EFAIL, "pair (seq %u, profile %u) has no finite alt path",
+                             hits[h0 + i].seq_idx, hits[h0 + i].profile_idx);
+                ns[i] = 0;
+            }
+            else if (ns[i] > cap[h0 + i])
+            {
+                rc = c->fail(DCP_EFAIL, "path of hit %u exceeds its step capacity", h0 + i);
+                ns[i] = 0;
+            }
+            host_steps.insert(host_steps.end(), st.begin() + soff[i], st.begin() + soff[i] + ns[i]);
+            total_steps += ns[i];
+            step_off[h0 + i + 1] = (uint32_t)total_steps;
+        }
+        h0 = h1;
+    }
+    if (rc) return rc;
+    if (total_steps > cap_steps || (total_steps && !steps_out)) return DCP_ENOMEM;
+    if (total_steps) std::memcpy(steps_out, host_steps.data(), total_steps * sizeof(dcp_step));
+    return DCP_OK;
+}
 
 static void last_range(dcp_gpu_ctx const *c, uint64_t *sumM, uint64_t *len, uint64_t *nq)
 {

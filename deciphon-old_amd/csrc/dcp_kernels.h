@@ -57,6 +57,29 @@ struct dcp_expand_tile
     uint32_t col0;
 };
 
+// ---- alt-path traceback for hits (viterbi_trace_kernel) ----------------------
+struct dcp_trace_args
+{
+    dcp_prof_meta const *profs;
+    uint32_t const *slot_of_pidx; // caller's profile index -> entry of profs[]
+    float const *emis_match;
+    float const *emis_insert;
+    float const *emis_null;
+    float const *trans8;
+    uint32_t const *seq_words;
+    uint32_t const *seq_woff;
+    uint32_t const *seq_len;
+    float const *xtrans;
+    dcp_hit const *hits;   // pairs to trace (seq_idx, profile_idx of the resident batch / DB)
+    unsigned nhits;
+    float *work;           // per hit: 3 x [L+1][ldk] + 5 x [L+1] floats
+    uint64_t const *work_off; // [nhits] float offset of each hit's work area
+    dcp_step *steps;
+    uint32_t const *step_off; // [nhits+1] capacity slices of steps[]
+    uint32_t *nsteps;         // [nhits] steps written; 0xffffffff = no path
+    float *alt_out;           // [nhits] alt log-likelihood recomputed by the trace
+};
+
 // ---- query-lane kernel (dcp_qlane.hip) --------------------------------------
 struct dcp_ql_prof
 {
@@ -117,6 +140,7 @@ int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
 int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream);
+void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);
 #ifdef __cplusplus

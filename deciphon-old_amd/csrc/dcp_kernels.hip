@@ -430,6 +430,365 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
 }
 
 // ============================================================================
+// Alt-path traceback for hits.  One wavefront per hit:
+//   forward: the same recursion, every M/I/D value and the specials stored in a
+//            per-hit work area (float32 [L+1][ldk] x 3 + 5 x [L+1]);
+//   backward: lane 0 walks from T(L) to S(0) re-deriving each arg-max from the
+//            stored values -- first maximum wins, candidates in the order the
+//            reference wires the transitions (src/model/protein_model.c:460-500,
+//            :322-340), which is also the oracle's order.
+// Produces imm_path steps {state_id, seqlen} (include/deciphon/model/protein_state.h).
+// Not a throughput kernel: hits are rare (lrt >= 10).
+// ============================================================================
+namespace
+{
+struct TraceView
+{
+    float *Mv, *Iv, *Dv; // [L+1][ldk]
+    float *N, *B, *E, *J, *C; // [L+1]
+    float const *ent, *mm, *im, *dm, *md, *dd, *mi, *ii;
+    float const *eM, *eI, *eN;
+    float const *xt;
+    uint32_t const *words;
+    unsigned ldk, M, L;
+};
+
+__device__ __forceinline__ unsigned window_at(uint32_t const *words, unsigned j)
+{
+    // rolling base-4 value of the (up to) 5 bases ending at position j (1-based rows)
+    unsigned w = 0;
+    unsigned const lo = j > 5u ? j - 5u : 0u;
+    for (unsigned p = lo; p < j; ++p)
+        w = (w << 2) | base_at(words, p);
+    return w & 1023u;
+}
+
+// P_k(jj): best predecessor of M_k leaving row jj; *arg: 0 = M_{k-1}, 1 = I_{k-1}, 2 = D_{k-1}, 3 = B
+__device__ float trace_P(TraceView const &v, unsigned jj, unsigned k, int *arg)
+{
+    float best = -__builtin_inff();
+    int a = -1;
+    if (k > 0)
+    {
+        size_t const o = (size_t)jj * v.ldk + k - 1;
+        float c0 = v.Mv[o] + v.mm[k], c1 = v.Iv[o] + v.im[k], c2 = v.Dv[o] + v.dm[k];
+        if (c0 > best) best = c0, a = 0;
+        if (c1 > best) best = c1, a = 1;
+        if (c2 > best) best = c2, a = 2;
+    }
+    float const cb = v.B[jj] + v.ent[k];
+    if (cb > best) best = cb, a = 3;
+    if (arg) *arg = a;
+    return best;
+}
+
+// Q_k(jj): best predecessor of I_k; *arg: 0 = M_k, 1 = I_k
+__device__ float trace_Q(TraceView const &v, unsigned jj, unsigned k, int *arg)
+{
+    size_t const o = (size_t)jj * v.ldk + k;
+    float best = -__builtin_inff();
+    int a = -1;
+    float c0 = v.Mv[o] + v.mi[k], c1 = v.Iv[o] + v.ii[k];
+    if (c0 > best) best = c0, a = 0;
+    if (c1 > best) best = c1, a = 1;
+    if (arg) *arg = a;
+    return best;
+}
+
+// predecessor maxima of the special emitting states; *arg 0 = first source, 1 = self loop
+__device__ float trace_PN(TraceView const &v, unsigned jj, int *arg)
+{
+    float best = -__builtin_inff();
+    int a = -1;
+    float c0 = (jj == 0 ? 0.0f : -__builtin_inff()) + v.xt[DCP_X_SN];
+    float c1 = v.N[jj] + v.xt[DCP_X_NN];
+    if (c0 > best) best = c0, a = 0;
+    if (c1 > best) best = c1, a = 1;
+    if (arg) *arg = a;
+    return best;
+}
+__device__ float trace_PJ(TraceView const &v, unsigned jj, int *arg)
+{
+    float best = -__builtin_inff();
+    int a = -1;
+    float c0 = v.E[jj] + v.xt[DCP_X_EJ], c1 = v.J[jj] + v.xt[DCP_X_JJ];
+    if (c0 > best) best = c0, a = 0;
+    if (c1 > best) best = c1, a = 1;
+    if (arg) *arg = a;
+    return best;
+}
+__device__ float trace_PC(TraceView const &v, unsigned jj, int *arg)
+{
+    float best = -__builtin_inff();
+    int a = -1;
+    float c0 = v.E[jj] + v.xt[DCP_X_EC], c1 = v.C[jj] + v.xt[DCP_X_CC];
+    if (c0 > best) best = c0, a = 0;
+    if (c1 > best) best = c1, a = 1;
+    if (arg) *arg = a;
+    return best;
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
+{
+    unsigned const lane = threadIdx.x;
+    unsigned const h = blockIdx.x;
+    if (h >= a.nhits) return;
+    dcp_hit const hit = a.hits[h];
+    dcp_prof_meta const pm = a.profs[a.slot_of_pidx[hit.profile_idx]];
+    unsigned const q = hit.seq_idx;
+    float const ni = neg_inf();
+
+    TraceView v;
+    v.ldk = pm.ldk;
+    v.M = pm.core_size;
+    v.L = a.seq_len[q];
+    v.words = a.seq_words + a.seq_woff[q];
+    v.xt = a.xtrans + (size_t)q * DCP_XSTRIDE;
+    float const *tb = a.trans8 + pm.trans_off;
+    v.ent = tb + (size_t)DCP_T_ENTRY * v.ldk, v.mm = tb + (size_t)DCP_T_MM * v.ldk;
+    v.im = tb + (size_t)DCP_T_IM * v.ldk, v.dm = tb + (size_t)DCP_T_DM * v.ldk;
+    v.md = tb + (size_t)DCP_T_MD * v.ldk, v.dd = tb + (size_t)DCP_T_DD * v.ldk;
+    v.mi = tb + (size_t)DCP_T_MI * v.ldk, v.ii = tb + (size_t)DCP_T_II * v.ldk;
+    v.eM = a.emis_match + pm.emis_off;
+    v.eI = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
+    v.eN = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
+    unsigned const L = v.L, ldk = v.ldk;
+    size_t const mat = (size_t)(L + 1) * ldk;
+    float *work = a.work + a.work_off[h];
+    v.Mv = work, v.Iv = work + mat, v.Dv = work + 2 * mat;
+    v.N = work + 3 * mat, v.B = v.N + (L + 1), v.E = v.B + (L + 1), v.J = v.E + (L + 1), v.C = v.J + (L + 1);
+
+    // ---- forward -----------------------------------------------------------------
+    unsigned const R = ldk / 64u; // nodes per lane, contiguous
+    unsigned const k0 = lane * R;
+    for (unsigned r = 0; r < R; ++r)
+        v.Mv[k0 + r] = v.Iv[k0 + r] = v.Dv[k0 + r] = ni; // row 0
+    if (lane == 0)
+    {
+        v.N[0] = ni, v.E[0] = ni, v.J[0] = ni, v.C[0] = ni;
+        v.B[0] = 0.0f + v.xt[DCP_X_SB];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+
+    for (unsigned j = 1; j <= L; ++j)
+    {
+        unsigned const w = window_at(v.words, j);
+        unsigned const maxl = j < 5u ? j : 5u;
+        float *Mj = v.Mv + (size_t)j * ldk, *Ij = v.Iv + (size_t)j * ldk, *Dj = v.Dv + (size_t)j * ldk;
+        for (unsigned r = 0; r < R; ++r)
+        {
+            unsigned const k = k0 + r;
+            float m = ni, iv = ni;
+            for (unsigned l = 1; l <= maxl; ++l)
+            {
+                unsigned const c = code_of(w, (int)l);
+                m = fmaxf(m, trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * ldk + k]);
+                iv = fmaxf(iv, trace_Q(v, j - l, k, nullptr) + v.eI[c]);
+            }
+            Mj[k] = m, Ij[k] = iv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        // delete chain to the fixed point (same construction as the scoring kernels)
+        float d_last = ni;
+        for (;;)
+        {
+            float const before = d_last;
+            float d = lane_shr1(d_last, ni); // D of node k0-1
+            for (unsigned r = 0; r < R; ++r)
+            {
+                unsigned const k = k0 + r;
+                d = k == 0 ? ni : fmaxf(Mj[k - 1] + v.md[k], d + v.dd[k]);
+                Dj[k] = d;
+            }
+            d_last = d;
+            if (!__any(d_last != before)) break;
+        }
+        float e = ni;
+        for (unsigned r = 0; r < R; ++r)
+            e = fmaxf(e, fmaxf(Mj[k0 + r], Dj[k0 + r]));
+        float const E = wave_max(e);
+        float N = ni, J = ni, C = ni;
+        for (unsigned l = 1; l <= maxl; ++l)
+        {
+            float const en = v.eN[code_of(w, (int)l)];
+            N = fmaxf(N, trace_PN(v, j - l, nullptr) + en);
+            J = fmaxf(J, trace_PJ(v, j - l, nullptr) + en);
+            C = fmaxf(C, trace_PC(v, j - l, nullptr) + en);
+        }
+        if (lane == 0)
+        {
+            v.N[j] = N, v.E[j] = E, v.J[j] = J, v.C[j] = C;
+            v.B[j] = fmaxf(fmaxf(N + v.xt[DCP_X_NB], E + v.xt[DCP_X_EB]), J + v.xt[DCP_X_JB]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- backward (lane 0) ---------------------------------------------------------
+    if (lane != 0) return;
+    float const alt = fmaxf(v.E[L] + v.xt[DCP_X_ET], v.C[L] + v.xt[DCP_X_CT]);
+    a.alt_out[h] = alt;
+    dcp_step *out = a.steps + a.step_off[h];
+    unsigned const cap = a.step_off[h + 1] - a.step_off[h];
+    unsigned n = 0;
+    bool ok = alt > ni;
+    enum { ST_S = 1, ST_N, ST_B, ST_E, ST_J, ST_C, ST_T, ST_M, ST_I, ST_D };
+    int st = ST_T;
+    unsigned k = 0, j = L;
+    auto push = [&](unsigned id, unsigned len) {
+        if (n < cap) out[n] = dcp_step{(uint16_t)id, (uint8_t)len, 0};
+        ++n;
+    };
+    unsigned const EXT = 3u << 14;
+    unsigned guard = 0, const_guard = 4u * (L + v.M) + 64u;
+    while (ok && guard++ < const_guard)
+    {
+        if (st == ST_T)
+        {
+            push(EXT | 7u, 0);
+            float c0 = v.E[j] + v.xt[DCP_X_ET], c1 = v.C[j] + v.xt[DCP_X_CT];
+            st = !(c1 > c0) ? ST_E : ST_C; // E->T was wired first
+        }
+        else if (st == ST_E)
+        {
+            push(EXT | 4u, 0);
+            // M_M, M_1..M_{M-1}, D_2..D_M (1-based): protein_model.c:494, :441-458
+            float best = ni;
+            int bs = -1;
+            unsigned bk = 0;
+            float const *Mj = v.Mv + (size_t)j * ldk, *Dj = v.Dv + (size_t)j * ldk;
+            float c = Mj[v.M - 1] + 0.0f;
+            if (c > best) best = c, bs = ST_M, bk = v.M - 1;
+            for (unsigned kk = 0; kk + 1 < v.M; ++kk)
+            {
+                c = Mj[kk] + 0.0f;
+                if (c > best) best = c, bs = ST_M, bk = kk;
+            }
+            for (unsigned kk = 1; kk < v.M; ++kk)
+            {
+                c = Dj[kk] + 0.0f;
+                if (c > best) best = c, bs = ST_D, bk = kk;
+            }
+            if (bs < 0) ok = false;
+            st = bs, k = bk;
+        }
+        else if (st == ST_M || st == ST_I || st == ST_N || st == ST_J || st == ST_C)
+        {
+            unsigned const w = window_at(v.words, j);
+            unsigned const maxl = j < 5u ? j : 5u;
+            float best = ni;
+            unsigned bl = 0;
+            for (unsigned l = 1; l <= maxl; ++l)
+            {
+                unsigned const c = code_of(w, (int)l);
+                float sc;
+                if (st == ST_M) sc = trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * ldk + k];
+                else if (st == ST_I) sc = trace_Q(v, j - l, k, nullptr) + v.eI[c];
+                else if (st == ST_N) sc = trace_PN(v, j - l, nullptr) + v.eN[c];
+                else if (st == ST_J) sc = trace_PJ(v, j - l, nullptr) + v.eN[c];
+                else sc = trace_PC(v, j - l, nullptr) + v.eN[c];
+                if (sc > best) best = sc, bl = l;
+            }
+            if (bl == 0) { ok = false; break; }
+            int arg = -1;
+            if (st == ST_M)
+            {
+                push(k + 1u, bl);
+                trace_P(v, j - bl, k, &arg);
+                j -= bl;
+                if (arg == 0) st = ST_M, k = k - 1;
+                else if (arg == 1) st = ST_I, k = k - 1;
+                else if (arg == 2) st = ST_D, k = k - 1;
+                else if (arg == 3) st = ST_B;
+                else ok = false;
+            }
+            else if (st == ST_I)
+            {
+                push((1u << 14) | (k + 1u), bl);
+                trace_Q(v, j - bl, k, &arg);
+                j -= bl;
+                if (arg == 0) st = ST_M;
+                else if (arg == 1) st = ST_I;
+                else ok = false;
+            }
+            else if (st == ST_N)
+            {
+                push(EXT | 2u, bl);
+                trace_PN(v, j - bl, &arg);
+                j -= bl;
+                st = arg == 0 ? ST_S : ST_N;
+                if (arg < 0) ok = false;
+            }
+            else if (st == ST_J)
+            {
+                push(EXT | 5u, bl);
+                trace_PJ(v, j - bl, &arg);
+                j -= bl;
+                st = arg == 0 ? ST_E : ST_J;
+                if (arg < 0) ok = false;
+            }
+            else
+            {
+                push(EXT | 6u, bl);
+                trace_PC(v, j - bl, &arg);
+                j -= bl;
+                st = arg == 0 ? ST_E : ST_C;
+                if (arg < 0) ok = false;
+            }
+        }
+        else if (st == ST_D)
+        {
+            push((2u << 14) | (k + 1u), 0);
+            if (k == 0) { ok = false; break; }
+            size_t const o = (size_t)j * ldk + k - 1;
+            float c0 = v.Mv[o] + v.md[k], c1 = v.Dv[o] + v.dd[k];
+            st = !(c1 > c0) ? ST_M : ST_D; // M_{k-1} -> D_k was wired first
+            k = k - 1;
+        }
+        else if (st == ST_B)
+        {
+            push(EXT | 3u, 0);
+            // S->B, N->B, E->B, J->B (protein_model.c:324-337)
+            float best = ni;
+            int bs = -1;
+            float c = (j == 0 ? 0.0f : ni) + v.xt[DCP_X_SB];
+            if (c > best) best = c, bs = ST_S;
+            c = v.N[j] + v.xt[DCP_X_NB];
+            if (c > best) best = c, bs = ST_N;
+            c = v.E[j] + v.xt[DCP_X_EB];
+            if (c > best) best = c, bs = ST_E;
+            c = v.J[j] + v.xt[DCP_X_JB];
+            if (c > best) best = c, bs = ST_J;
+            if (bs < 0) ok = false;
+            st = bs;
+        }
+        else // ST_S
+        {
+            push(EXT | 1u, 0);
+            if (j != 0) ok = false;
+            break;
+        }
+    }
+    if (st != ST_S) ok = false;
+    unsigned const m = n < cap ? n : cap;
+    for (unsigned i = 0; i < m / 2; ++i)
+    {
+        dcp_step t = out[i];
+        out[i] = out[m - 1 - i];
+        out[m - 1 - i] = t;
+    }
+    a.nsteps[h] = ok ? n : 0xffffffffu;
+}
+
+extern "C" void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream)
+{
+    hipLaunchKernelGGL(viterbi_trace_kernel, dim3(nhits), dim3(64), 0, (hipStream_t)stream, *a);
+}
+
+// ============================================================================
 // Emission-table expansion: out[code][k] for a tile of 64 nodes per block.
 // Same probability-domain formula as dcp_frame_table_host (dcp_model.cpp).
 // ============================================================================

@@ -13,7 +13,10 @@
 // in double in the probability domain and rounded once to float32 (imm_float).
 #include "dcp_host.h"
 
+#include <cinttypes>
 #include <cmath>
+#include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -458,6 +461,193 @@ void dcp_partition_by_cells(unsigned const *core_sizes, unsigned nprofiles,
         part_begin[g] = p;
     }
     part_begin[npartitions] = nprofiles;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// Hit post-processing: state names, codon decode, product rows
+// ---------------------------------------------------------------------------
+namespace
+{
+// imm frame state: probability of emitting word x (1..5 bases) given base probs b and
+// codon marginals C (5x5x5, index 4 = wildcard) -- the formula of dcp_frame_table_host,
+// evaluated for one word.
+double frame_prob_word(double const *b, double const *C, double e, double f, uint8_t const *x, unsigned len)
+{
+    auto c3 = [&](int p, int q, int r) { return C[p * 25 + q * 5 + r]; };
+    auto s1 = [&](int p) { return c3(p, 4, 4) + c3(4, p, 4) + c3(4, 4, p); };
+    auto s2 = [&](int p, int q) { return c3(4, p, q) + c3(p, 4, q) + c3(p, q, 4); };
+    double const e2 = e * e, f2 = f * f;
+    switch (len)
+    {
+    case 1: return e2 * f2 / 3.0 * s1(x[0]);
+    case 2:
+        return 2.0 * e * f2 * f / 3.0 * s2(x[0], x[1]) +
+               e2 * e * f / 3.0 * (b[x[1]] * s1(x[0]) + b[x[0]] * s1(x[1]));
+    case 3:
+        return f2 * f2 * c3(x[0], x[1], x[2]) +
+               4.0 * e2 * f2 / 9.0 * (b[x[0]] * s2(x[1], x[2]) + b[x[1]] * s2(x[0], x[2]) + b[x[2]] * s2(x[0], x[1])) +
+               e2 * e2 / 9.0 * (b[x[0]] * b[x[1]] * s1(x[2]) + b[x[0]] * b[x[2]] * s1(x[1]) + b[x[1]] * b[x[2]] * s1(x[0]));
+    case 4:
+    {
+        double one = b[x[0]] * c3(x[1], x[2], x[3]) + b[x[1]] * c3(x[0], x[2], x[3]) +
+                     b[x[2]] * c3(x[0], x[1], x[3]) + b[x[3]] * c3(x[0], x[1], x[2]);
+        double two = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+            {
+                int r[2], n = 0;
+                for (int k = 0; k < 4; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                two += b[x[i]] * b[x[j]] * s2(r[0], r[1]);
+            }
+        return e * f2 * f / 2.0 * one + e2 * e * f / 9.0 * two;
+    }
+    case 5:
+    {
+        double s = 0;
+        for (int i = 0; i < 5; ++i)
+            for (int j = i + 1; j < 5; ++j)
+            {
+                int r[3], n = 0;
+                for (int k = 0; k < 5; ++k)
+                    if (k != i && k != j) r[n++] = x[k];
+                s += b[x[i]] * b[x[j]] * c3(r[0], r[1], r[2]);
+            }
+        return e2 * f2 / 10.0 * s;
+    }
+    default: return std::numeric_limits<double>::quiet_NaN();
+    }
+}
+} // namespace
+
+extern "C" {
+
+// protein_state_name: src/model/protein_state.c:5-39
+unsigned dcp_state_name(unsigned id, char name[8])
+{
+    unsigned const msb = id & (3u << 14);
+    if (msb == (3u << 14))
+    {
+        static char const ext[] = "RSNBEJCT";
+        unsigned i = id & 0x3FFFu;
+        name[0] = i < 8 ? ext[i] : '?';
+        name[1] = '\0';
+        return 1;
+    }
+    name[0] = msb == 0 ? 'M' : msb == (1u << 14) ? 'I' : 'D';
+    return (unsigned)snprintf(name + 1, 7, "%u", id & 0x3FFFu) + 1;
+}
+
+char dcp_gc_decode(uint8_t const codon[3])
+{
+    if (codon[0] > 3 || codon[1] > 3 || codon[2] > 3) return 'X';
+    return g_codons.aa[codon[0] * 16 + codon[1] * 4 + codon[2]];
+}
+
+// protein_profile_decode (src/model/protein_profile.c:306-331): the distribution is the
+// insert dist for I states, the node's match dist for M states, the null dist otherwise;
+// imm_frame_cond_decode = arg-max over the 64 codons of p(fragment, codon).
+int dcp_profile_decode(dcp_profile const *p, uint8_t const *frag, unsigned len, unsigned state_id,
+                       uint8_t codon[3])
+{
+    if (!p || !frag || !codon || len < 1 || len > 5) return DCP_EINVAL;
+    for (unsigned i = 0; i < len; ++i)
+        if (frag[i] > 3) return DCP_EINVAL;
+    unsigned const msb = state_id & (3u << 14);
+    float const *dist;
+    if (msb == (1u << 14))
+        dist = p->insert_dist;
+    else if (msb == 0)
+    {
+        unsigned k = (state_id & 0x3FFFu) - 1u; // protein_state_idx
+        if (k >= p->core_size) return DCP_EINVAL;
+        dist = &p->match_dist[(size_t)k * DCP_NDIST];
+    }
+    else if (state_id == ((3u << 14) | 1u) || state_id == ((3u << 14) | 3u) ||
+             state_id == ((3u << 14) | 4u) || state_id == ((3u << 14) | 7u) || msb == (2u << 14))
+        return DCP_EINVAL; // mute states emit nothing: assert(!protein_state_is_mute) :310
+    else
+        dist = p->null_dist;
+    double b[4], full[125];
+    for (int i = 0; i < 4; ++i)
+        b[i] = std::exp((double)dist[i]);
+    double const e = (double)p->epsilon, f = 1.0 - e;
+    double best = -1.0;
+    codon[0] = codon[1] = codon[2] = 4;
+    for (int a = 0; a < 4; ++a)
+        for (int bb = 0; bb < 4; ++bb)
+            for (int cc = 0; cc < 4; ++cc)
+            {
+                double const pc = std::exp((double)dist[4 + a * 25 + bb * 5 + cc]);
+                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 5; ++j)
+                        for (int k = 0; k < 5; ++k)
+                            full[i * 25 + j * 5 + k] =
+                                ((i == 4 || i == a) && (j == 4 || j == bb) && (k == 4 || k == cc)) ? pc : 0.0;
+                double const v = frame_prob_word(b, full, e, f, frag, len);
+                if (v >= best)
+                {
+                    best = v;
+                    codon[0] = (uint8_t)a, codon[1] = (uint8_t)bb, codon[2] = (uint8_t)cc;
+                }
+            }
+    return best >= 0.0 ? DCP_OK : DCP_EINVAL;
+}
+
+char const *dcp_prod_header(void)
+{
+    return "scan_id\tseq_id\tprofile_name\tabc_name\talt_loglik\tnull_loglik\tprofile_typeid\tversion\tmatch\n";
+}
+
+// prod_fwrite + protein_match_write_func (src/server/prod.c:13-41,153-181; protein_match.c:21-56)
+long dcp_prod_format_row(char *buf, size_t cap, int64_t scan_id, int64_t seq_id,
+                         char const *profile_name, char const *abc_name, double alt_loglik,
+                         double null_loglik, char const *profile_typeid, char const *version,
+                         dcp_profile const *prof, uint8_t const *seq, unsigned seq_len,
+                         struct dcp_step const *steps, unsigned nsteps)
+{
+    if (!buf || !prof || !seq || (nsteps && !steps)) return -1;
+    std::string out;
+    char head[512];
+    int n = snprintf(head, sizeof head, "%" PRId64 "\t%" PRId64 "\t%s\t%s\t%.17g\t%.17g\t%s\t%s\t", scan_id,
+                     seq_id, profile_name ? profile_name : "", abc_name ? abc_name : "", alt_loglik,
+                     null_loglik, profile_typeid ? profile_typeid : "", version ? version : "");
+    if (n < 0 || (size_t)n >= sizeof head) return -1;
+    out.assign(head, (size_t)n);
+    unsigned start = 0;
+    for (unsigned i = 0; i < nsteps; ++i)
+    {
+        unsigned const len = steps[i].seqlen, id = steps[i].state_id;
+        if (start + len > seq_len) return -1;
+        if (i > 0) out.push_back(';');
+        for (unsigned k = 0; k < len; ++k)
+            out.push_back("ACGT"[seq[start + k] & 3]);
+        out.push_back(',');
+        char name[8];
+        dcp_state_name(id, name);
+        out += name;
+        out.push_back(',');
+        bool const mute = len == 0; // S, B, E, T and D states (protein_state_is_mute)
+        if (!mute)
+        {
+            uint8_t codon[3];
+            if (dcp_profile_decode(prof, seq + start, len, id, codon)) return -1;
+            for (int k = 0; k < 3; ++k)
+                out.push_back("ACGT"[codon[k] & 3]);
+            out.push_back(',');
+            out.push_back(dcp_gc_decode(codon));
+        }
+        else
+            out.push_back(',');
+        start += len;
+    }
+    out.push_back('\n');
+    if (out.size() + 1 > cap) return -1;
+    std::memcpy(buf, out.data(), out.size());
+    buf[out.size()] = '\0';
+    return (long)out.size();
 }
 
 } // extern "C"

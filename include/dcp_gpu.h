@@ -232,6 +232,49 @@ int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *, unsigned i,
 int dcp_gpu_fetch_scores(dcp_gpu_ctx *, float *null_out, float *alt_out);
 int dcp_gpu_fetch_hits(dcp_gpu_ctx *, struct dcp_hit *hits, unsigned cap,
                        unsigned *nhits);
+/* ------------------------------------------------------------------------ */
+/* Hits -> paths -> product rows                           */
+/* ------------------------------------------------------------------------ */
+/* imm_step {state_id, seqlen}: state ids as include/deciphon/model/protein_state.h:7-21 */
+struct dcp_step
+{
+    uint16_t state_id;
+    uint8_t seqlen;
+    uint8_t reserved;
+};
+
+/* Alt-model Viterbi paths (what imm_dp_viterbi leaves in prod.path,
+ * src/server/scan_thread.c:117) of `nhits` (seq_idx, profile_idx) pairs of the
+ * resident batch / DB, computed on the device. Flags as in the scan that found
+ * them. steps_out receives the paths back to back; step_off[nhits+1] their
+ * offsets; alt_out (may be NULL) the log-likelihood the trace recomputed (equal
+ * to the scan's). DCP_ENOMEM if cap_steps is too small (step_off[nhits] then
+ * holds the needed total), DCP_EFAIL if a pair has no finite path. */
+int dcp_gpu_trace_paths(dcp_gpu_ctx *, struct dcp_hit const *hits, unsigned nhits,
+                        int multi_hits, int hmmer3_compat, struct dcp_step *steps_out,
+                        unsigned cap_steps, uint32_t *step_off, float *alt_out);
+
+/* protein_state_name (src/model/protein_state.c:5-39): "M12", "I3", "N"... */
+unsigned dcp_state_name(unsigned state_id, char name[8]);
+/* protein_profile_decode (src/model/protein_profile.c:306-331) = imm_frame_cond_decode:
+ * most likely codon (ids 0..3) of a 1..5-nt fragment emitted by `state_id`. */
+int dcp_profile_decode(dcp_profile const *, uint8_t const *frag, unsigned len,
+                       unsigned state_id, uint8_t codon[3]);
+/* imm_gc_decode(1, codon): amino acid letter of a codon, '*' for stops */
+char dcp_gc_decode(uint8_t const codon[3]);
+/* One product row exactly as prod_fwrite + protein_match_write_func write it
+ * (src/server/prod.c:13-41,153-181; src/server/protein_match.c:21-56), without
+ * the trailing newline handling changed: returns the number of bytes written to
+ * buf (incl. the final '\n'), or -1 if cap is too small. seq: symbol ids. */
+long dcp_prod_format_row(char *buf, size_t cap, int64_t scan_id, int64_t seq_id,
+                         char const *profile_name, char const *abc_name,
+                         double alt_loglik, double null_loglik,
+                         char const *profile_typeid, char const *version,
+                         dcp_profile const *prof, uint8_t const *seq, unsigned seq_len,
+                         struct dcp_step const *steps, unsigned nsteps);
+/* The header line prod_fclose writes (src/server/prod.c:119-121). */
+char const *dcp_prod_header(void);
+
 /* Work accounting of the last scan (or of a full scan if none ran yet):
  * alt-model DP cells = sum over pairs of core_size * L (the Gcell/s numerator)
  * and the algorithmic bytes of SURVEY.md §8(d): sum over pairs of

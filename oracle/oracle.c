@@ -1010,6 +1010,48 @@ int orc_viterbi(struct orc_profile const *p, int alt, unsigned char const *seq,
                            path_len, nsteps);
 }
 
+/* Score of a GIVEN path in the model: start lprob + transitions + emissions, accumulated in
+ * the DP's own order ((prev + trans) + emis).  NaN if the path is not a path of the graph
+ * (unknown state, missing transition, wrong start/end, fragments not covering the sequence). */
+ofloat orc_path_score(struct orc_profile const *p, int alt, unsigned char const *seq, unsigned L,
+                      uint16_t const *path_state, uint8_t const *path_len, unsigned nsteps)
+{
+    struct ohmm const *h = alt ? &p->alt : &p->null;
+    ofloat score = 0;
+    int prev = -1;
+    unsigned pos = 0;
+    for (unsigned i = 0; i < nsteps; ++i)
+    {
+        int cur = -1;
+        for (int s = 0; s < h->nstates; ++s)
+            if (h->states[s].id == path_state[i])
+            {
+                cur = s;
+                break;
+            }
+        if (cur < 0) return (ofloat)NAN;
+        unsigned len = path_len[i];
+        if (h->states[cur].emitting ? (len < 1 || len > 5) : len != 0) return (ofloat)NAN;
+        if (pos + len > L) return (ofloat)NAN;
+        if (i == 0)
+        {
+            if (cur != h->start) return (ofloat)NAN;
+            score = h->start_lp;
+        }
+        else
+        {
+            int t = hmm_trans_idx(h, prev, cur);
+            if (t < 0) return (ofloat)NAN;
+            score = score + h->trans[t].lp;
+        }
+        if (len) score = score + h->states[cur].tbl[orc_word_code(seq + pos, len)];
+        pos += len;
+        prev = cur;
+    }
+    if (prev != h->end || pos != L) return (ofloat)NAN;
+    return score;
+}
+
 /* ======================================================================== */
 /* End-indexed score-only recursion                       */
 /* ======================================================================== */
@@ -1178,6 +1220,33 @@ ofloat orc_profile_decode(struct orc_profile const *p, unsigned char const *frag
                 }
             }
     return best;
+}
+
+/* joint log p(fragment, codon) under the distribution protein_profile_decode picks for state_id */
+ofloat orc_profile_codon_lprob(struct orc_profile const *p, unsigned char const *frag,
+                               unsigned len, unsigned state_id, unsigned char const codon[3])
+{
+    struct orc_nuclt_dist const *d;
+    unsigned msb = state_id & (3u << 14);
+    if (msb == ORC_INSERT_STATE)
+        d = &p->insert_d;
+    else if (msb == ORC_MATCH_STATE)
+        d = &p->match_d[(state_id & 0x3FFF) - 1];
+    else
+        d = &p->null_d;
+    ofloat le = (ofloat)O_LOG(p->eps), l1 = (ofloat)O_LOG((ofloat)1 - p->eps);
+    if (len < 1 || len > 5) return (ofloat)NAN;
+    unsigned a = codon[0], b = codon[1], c = codon[2];
+    ofloat lp = d->codonm[a * 25 + b * 5 + c];
+    ofloat cm[125];
+    for (unsigned i = 0; i < 5; ++i)
+        for (unsigned j = 0; j < 5; ++j)
+            for (unsigned k = 0; k < 5; ++k)
+            {
+                int ok = (i == 4 || i == a) && (j == 4 || j == b) && (k == 4 || k == c);
+                cm[i * 25 + j * 5 + k] = ok ? lp : NEG_INF;
+            }
+    return frame_lprob(d->nucltp, cm, le, l1, frag, len);
 }
 
 /* protein_state_name: protein_state.c:5-39 */

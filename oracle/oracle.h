@@ -155,6 +155,10 @@ int orc_viterbi(struct orc_profile const *p, int alt, unsigned char const *seq,
                 unsigned L, ofloat *loglik, uint16_t *path_state,
                 uint8_t *path_len, unsigned *nsteps);
 
+/* Score of a given path (validates it is a path of the model graph); NaN if it is not. */
+ofloat orc_path_score(struct orc_profile const *p, int alt, unsigned char const *seq, unsigned L,
+                      uint16_t const *path_state, uint8_t const *path_len, unsigned nsteps);
+
 /* Score-only, end-indexed recursion of SURVEY Appendix B (the formulation the
  * HIP kernels implement); same float association as orc_viterbi. */
 int orc_viterbi_fast(struct orc_profile const *p, unsigned char const *seq,
@@ -178,6 +182,10 @@ ofloat orc_lrt(ofloat null_loglik, ofloat alt_loglik);
 ofloat orc_profile_decode(struct orc_profile const *p, unsigned char const *frag,
                           unsigned len, unsigned state_id,
                           unsigned char codon[3]);
+
+/* joint log p(fragment, codon) for one given codon (what the decode maximises) */
+ofloat orc_profile_codon_lprob(struct orc_profile const *p, unsigned char const *frag,
+                               unsigned len, unsigned state_id, unsigned char const codon[3]);
 
 /* protein_state_name (protein_state.c:5-39) */
 unsigned orc_state_name(unsigned id, char name[8]);

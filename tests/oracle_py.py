@@ -97,6 +97,18 @@ class Profile:
         return lp, "".join("ACGT"[b] if b < 4 else "X" for b in cod.raw[:3])
 
 
+    def path_score(self, alt, seq: bytes, path):
+        """score of a given path [(state_id, seqlen), ...] in this model; NaN if it is not a path"""
+        st = np.array([s for s, _ in path], np.uint16)
+        ln = np.array([l for _, l in path], np.uint8)
+        return self.orc.lib.orc_path_score(self.h, int(alt), seq, len(seq), st.ctypes.data, ln.ctypes.data, len(path))
+
+    def codon_lprob(self, frag: bytes, state_id: int, codon: str):
+        """joint log p(fragment, codon) -- what protein_profile_decode maximises over codons"""
+        return self.orc.lib.orc_profile_codon_lprob(self.h, frag, len(frag), state_id,
+                                                   bytes("ACGT".index(c) for c in codon))
+
+
 class Oracle:
     def __init__(self, bits=32):
         build_oracle()
@@ -124,6 +136,10 @@ class Oracle:
             C.c_char_p, C.c_uint, C.POINTER(fl), C.POINTER(fl)]
         lib.orc_profile_decode.restype = fl
         lib.orc_profile_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_uint, C.c_char_p]
+        lib.orc_path_score.restype = fl
+        lib.orc_path_score.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint]
+        lib.orc_profile_codon_lprob.restype = fl
+        lib.orc_profile_codon_lprob.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_uint, C.c_char_p]
         lib.orc_state_name.argtypes = [C.c_uint, C.c_char_p]
         lib.orc_lrt.restype = fl
         lib.orc_lrt.argtypes = [fl, fl]
