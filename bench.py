@@ -41,6 +41,8 @@ WORKLOADS = {
     # name: (nprofiles, core-size rule, query length, queries per step per GPU, total queries)
     "c3": dict(nprof=20000, qlen=1000, qstep=1000, label="C3 Pfam-A-like 20k profiles x 1 kbp queries"),
     "c2": dict(nprof=1000, qlen=300, qstep=1000, label="C2 1k-profile synthetic DB x 300 bp queries"),
+    # mixed-length stress (BASELINE configs[4]): M log-uniform 50..2000 (seed 50), L log-uniform 100..10000
+    "c5": dict(nprof=20000, qlen=0, qstep=1000, label="C5 mixed-length stress: 20k profiles (50-2000 states) x queries 100 bp-10 kbp"),
 }
 
 
@@ -48,11 +50,22 @@ def core_sizes_for(workload, nprof):
     if workload == "c2":
         p = np.arange(nprof)
         return (100 + (p * 37) % 201).astype(np.uint32)
+    if workload == "c5":
+        rng = np.random.default_rng(50)
+        return np.round(np.exp(rng.uniform(np.log(50.0), np.log(2000.0), nprof))).astype(np.uint32)
     rng = np.random.default_rng(20000)
     return np.clip(np.round(np.exp(rng.normal(np.log(150.0), 0.6, nprof))), 30, 2000).astype(np.uint32)
 
 
 def make_queries(q_begin, q_end, qlen):
+    """qlen > 0: fixed-length batch [n, qlen]; qlen == 0: list of log-uniform 100..10000-nt queries."""
+    if qlen == 0:
+        out = []
+        for q in range(q_begin, q_end):
+            rng = np.random.default_rng(0x5E9 + q)
+            n = int(round(np.exp(rng.uniform(np.log(100.0), np.log(10000.0)))))
+            out.append(rng.integers(0, 4, n, dtype=np.uint8))
+        return out
     out = np.empty((q_end - q_begin, qlen), np.uint8)
     for i, q in enumerate(range(q_begin, q_end)):
         out[i] = np.random.default_rng(0x5E9 + q).integers(0, 4, qlen, dtype=np.uint8)
@@ -145,8 +158,11 @@ def main():
     # ---- resident queries: every step scans its own distinct batch --------------------------------
     nsteps = args.steps + args.warmup
     queries = make_queries(0, nsteps * qstep, qlen)
-    off = (np.arange(nsteps * qstep + 1, dtype=np.uint64) * qlen).astype(np.uint32)
-    sc.upload_seqs_flat(queries.reshape(-1), off)
+    if qlen:
+        off = (np.arange(nsteps * qstep + 1, dtype=np.uint64) * qlen).astype(np.uint32)
+        sc.upload_seqs_flat(queries.reshape(-1), off)
+    else:
+        sc.upload_seqs(queries)
     del queries
 
     cap = 1 << 16
@@ -231,7 +247,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{wl['label']}: {nprof} sampled profiles (sum M={int(sizes.sum())}, mean {sizes.mean():.0f}), "
-                            f"{qstep} distinct {qlen}-nt queries per step, multi_hits, lrt>=10",
+                            f"{qstep} distinct {str(qlen) + '-nt' if qlen else '100-10000-nt'} queries per step, multi_hits, lrt>=10",
                 "profiles_per_gpu": e - b, "queries_per_step": qstep, "query_len": qlen,
                 "parallelism": f"profile-shard x{world}" + (", RCCL hit all-gather per step" if world > 1 else ""),
             },
@@ -258,7 +274,7 @@ def main():
             },
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and qlen:
             out["cpu_baseline"] = cpu_baseline(dcp, sizes, args.workload, qlen)
         print(json.dumps(out))
     sc.close()

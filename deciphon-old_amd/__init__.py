@@ -138,7 +138,7 @@ def _load():
         "dcp_gpu_scan_range": (I, [P, C.POINTER(ScanParams), U, U]),
         "dcp_gpu_set_hit_buffer": (I, [P, P, U, P]),
         "dcp_gpu_last_scan_launch_info": (I, [P, U, C.POINTER(LaunchInfo)]),
-        "dcp_gpu_trace_paths": (I, [P, P, U, I, I, P, U, P, P]),
+        "dcp_gpu_trace_paths": (I, [P, P, U, I, I, I, P, U, P, P]),
         "dcp_state_name": (U, [U, C.c_char_p]),
         "dcp_profile_decode": (I, [P, P, U, U, P]),
         "dcp_gc_decode": (C.c_char, [P]),
@@ -449,9 +449,9 @@ class Scanner:
         self._check(lib.dcp_gpu_fetch_scores(self._c, nl.ctypes.data, al.ctypes.data))
         return nl, al
 
-    def trace_paths(self, hits, multi_hits=True, hmmer3_compat=False):
-        """Alt Viterbi paths of the given hit records, computed on the device: a list of
-        STEP_DTYPE arrays, plus the alt log-likelihoods the trace recomputed."""
+    def trace_paths(self, hits, multi_hits=True, hmmer3_compat=False, null_model=False):
+        """Viterbi paths (alt model, or null model if null_model) of the given hit records, computed
+        on the device: a list of STEP_DTYPE arrays, plus the log-likelihoods the trace recomputed."""
         h = np.ascontiguousarray(hits, HIT_DTYPE)
         n = len(h)
         off = np.zeros(n + 1, np.uint32)
@@ -460,7 +460,8 @@ class Scanner:
                       for q, p in zip(h["seq_idx"], h["profile_idx"]))) if n else 0
         steps = np.zeros(max(cap, 1), STEP_DTYPE)
         self._check(lib.dcp_gpu_trace_paths(self._c, h.ctypes.data, n, int(multi_hits), int(hmmer3_compat),
-                                            steps.ctypes.data, cap, off.ctypes.data, alt.ctypes.data))
+                                            int(null_model), steps.ctypes.data, cap, off.ctypes.data,
+                                            alt.ctypes.data))
         return [steps[off[i]:off[i + 1]].copy() for i in range(n)], alt
 
     def hits(self, cap=1 << 20):

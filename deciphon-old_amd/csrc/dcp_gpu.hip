@@ -867,8 +867,9 @@ int dcp_gpu_fetch_hits(dcp_gpu_ctx *c, struct dcp_hit *hits, unsigned cap, unsig
 // Hits -> alt paths (device traceback)
 // ---------------------------------------------------------------------------
 int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhits,
-                        int multi_hits, int hmmer3_compat, struct dcp_step *steps_out,
-                        unsigned cap_steps, uint32_t *step_off, float *alt_out)
+                        int multi_hits, int hmmer3_compat, int null_model,
+                        struct dcp_step *steps_out, unsigned cap_steps, uint32_t *step_off,
+                        float *alt_out)
 {
     if (!c || !step_off || (nhits && !hits)) return DCP_EINVAL;
     if (c->nprof == 0 || c->nseqs == 0) return c->fail(DCP_EINVAL, "no DB / sequences resident");
@@ -944,6 +945,7 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
         ta.step_off = d_soff.p;
         ta.nsteps = d_nsteps.p;
         ta.alt_out = d_alt.p;
+        ta.null_model = null_model ? 1 : 0;
         dcp_launch_trace(&ta, n, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -77,7 +77,8 @@ struct dcp_trace_args
     dcp_step *steps;
     uint32_t const *step_off; // [nhits+1] capacity slices of steps[]
     uint32_t *nsteps;         // [nhits] steps written; 0xffffffff = no path
-    float *alt_out;           // [nhits] alt log-likelihood recomputed by the trace
+    float *alt_out;           // [nhits] log-likelihood recomputed by the trace
+    int null_model;           // 0: alt model path (S..T); 1: null model path (R steps)
 };
 
 // ---- query-lane kernel (dcp_qlane.hip) --------------------------------------

@@ -559,6 +559,52 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
     v.Mv = work, v.Iv = work + mat, v.Dv = work + 2 * mat;
     v.N = work + 3 * mat, v.B = v.N + (L + 1), v.E = v.B + (L + 1), v.J = v.E + (L + 1), v.C = v.J + (L + 1);
 
+    // ---- null model (one state R, src/model/protein_model.c:223-225,316-320) --------------
+    if (a.null_model)
+    {
+        if (lane != 0) return;
+        float *Rv = v.N; // [L+1]
+        Rv[0] = ni;
+        auto PR = [&](unsigned jj) { return jj == 0 ? 0.0f : Rv[jj] + v.xt[DCP_X_RR]; };
+        for (unsigned j = 1; j <= L; ++j)
+        {
+            unsigned const w = window_at(v.words, j);
+            float r = ni;
+            for (unsigned l = 1; l <= (j < 5u ? j : 5u); ++l)
+                r = fmaxf(r, PR(j - l) + v.eN[code_of(w, (int)l)]);
+            Rv[j] = r;
+        }
+        a.alt_out[h] = Rv[L];
+        dcp_step *out = a.steps + a.step_off[h];
+        unsigned const cap = a.step_off[h + 1] - a.step_off[h];
+        unsigned n = 0, j = L;
+        bool ok = Rv[L] > ni;
+        while (ok && j > 0)
+        {
+            unsigned const w = window_at(v.words, j);
+            float best = ni;
+            unsigned bl = 0;
+            for (unsigned l = 1; l <= (j < 5u ? j : 5u); ++l)
+            {
+                float sc = PR(j - l) + v.eN[code_of(w, (int)l)];
+                if (sc > best) best = sc, bl = l;
+            }
+            if (bl == 0) { ok = false; break; }
+            if (n < cap) out[n] = dcp_step{(uint16_t)((3u << 14) | 0u), (uint8_t)bl, 0};
+            ++n;
+            j -= bl;
+        }
+        unsigned const m = n < cap ? n : cap;
+        for (unsigned i = 0; i < m / 2; ++i)
+        {
+            dcp_step t = out[i];
+            out[i] = out[m - 1 - i];
+            out[m - 1 - i] = t;
+        }
+        a.nsteps[h] = ok ? n : 0xffffffffu;
+        return;
+    }
+
     // ---- forward -----------------------------------------------------------------
     unsigned const R = ldk / 64u; // nodes per lane, contiguous
     unsigned const k0 = lane * R;

@@ -243,16 +243,18 @@ struct dcp_step
     uint8_t reserved;
 };
 
-/* Alt-model Viterbi paths (what imm_dp_viterbi leaves in prod.path,
- * src/server/scan_thread.c:117) of `nhits` (seq_idx, profile_idx) pairs of the
- * resident batch / DB, computed on the device. Flags as in the scan that found
+/* Viterbi paths (what imm_dp_viterbi leaves in prod.path,
+ * src/server/scan_thread.c:115-117) of `nhits` (seq_idx, profile_idx) pairs of the
+ * resident batch / DB, computed on the device: null_model == 0 -> alt model
+ * (S ... T), != 0 -> null model (R steps). Flags as in the scan that found
  * them. steps_out receives the paths back to back; step_off[nhits+1] their
  * offsets; alt_out (may be NULL) the log-likelihood the trace recomputed (equal
  * to the scan's). DCP_ENOMEM if cap_steps is too small (step_off[nhits] then
  * holds the needed total), DCP_EFAIL if a pair has no finite path. */
 int dcp_gpu_trace_paths(dcp_gpu_ctx *, struct dcp_hit const *hits, unsigned nhits,
-                        int multi_hits, int hmmer3_compat, struct dcp_step *steps_out,
-                        unsigned cap_steps, uint32_t *step_off, float *alt_out);
+                        int multi_hits, int hmmer3_compat, int null_model,
+                        struct dcp_step *steps_out, unsigned cap_steps, uint32_t *step_off,
+                        float *alt_out);
 
 /* protein_state_name (src/model/protein_state.c:5-39): "M12", "I3", "N"... */
 unsigned dcp_state_name(unsigned state_id, char name[8]);

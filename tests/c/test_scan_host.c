@@ -1,0 +1,239 @@
+/*
+ * C-level parity test of the host layer (include/deciphon_host.h) on the GPU.
+ *
+ * Part 1 follows what the reference checks in test/protein_profile.c (sampled M=2
+ * profile, eps 0.1, 32-nt query): setup(0) is RC_EINVAL; null loglik, path length and
+ * end steps; alt loglik for both entry distributions, path ends, decoded codons.
+ * Part 2 drives profile_reader + thread_run over a small resident DB with a planted
+ * domain and checks the product rows.
+ *
+ * Expected values are the reference's goldens (float32 tolerance 5e-5 relative,
+ * test/hope_support.h:26).  Exit status = number of failed checks.
+ */
+#include "deciphon_host.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int failed;
+#define CHECK(cond)                                                            \
+    do                                                                         \
+    {                                                                          \
+        if (!(cond))                                                           \
+        {                                                                      \
+            fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #cond); \
+            failed++;                                                          \
+        }                                                                      \
+    } while (0)
+#define NEAR(a, b) CHECK(fabs((double)(a) - (double)(b)) <= 5e-5 * fabs((double)(b)))
+
+static char const query[] = "ATGAAACGCATTAGCACCACCATTACCACCAC";
+static char const *const want_codons[10] = {"ATG", "AAA", "CGC", "ATA", "GCA", "CCA", "CCT", "TAC", "CAC", "CAC"};
+
+static void golden_profile(enum entry_dist entry, double want_alt)
+{
+    struct imm_nuclt const *nuclt = &imm_dna_iupac;
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, nuclt);
+    struct protein_profile prof;
+    protein_profile_init(&prof, "accession", &imm_amino_iupac, &code, protein_cfg(entry, 0.1f));
+    CHECK(protein_profile_sample(&prof, 1, 2) == RC_OK);
+
+    struct imm_seq seq = imm_seq(IMM_STR(query), prof.super.code->abc);
+    CHECK(protein_profile_setup(&prof, 0, true, false) == RC_EINVAL);
+    CHECK(protein_profile_setup(&prof, imm_seq_size(&seq), true, false) == RC_OK);
+
+    /* null model */
+    struct imm_prod prod = imm_prod();
+    struct imm_task *task = imm_task_new(&prof.null.dp);
+    CHECK(task != NULL);
+    CHECK(imm_task_setup(task, &seq) == IMM_OK);
+    CHECK(imm_dp_viterbi(&prof.null.dp, task, &prod) == IMM_OK);
+    NEAR(prod.loglik, -48.9272687711);
+    CHECK(imm_path_nsteps(&prod.path) == 11);
+    char name[IMM_STATE_NAME_SIZE];
+    CHECK(imm_path_step(&prod.path, 0)->seqlen == 3);
+    CHECK(imm_path_step(&prod.path, 0)->state_id == PROTEIN_R_STATE);
+    protein_state_name(imm_path_step(&prod.path, 0)->state_id, name);
+    CHECK(strcmp(name, "R") == 0);
+    CHECK(imm_path_step(&prod.path, 10)->seqlen == 2);
+    CHECK(imm_path_step(&prod.path, 10)->state_id == PROTEIN_R_STATE);
+    imm_prod_reset(&prod);
+    imm_task_del(task);
+
+    /* alt model */
+    struct imm_dp const *dp = profile_alt_dp(&prof.super);
+    task = imm_task_new(dp);
+    CHECK(imm_task_setup(task, &seq) == IMM_OK);
+    CHECK(imm_dp_viterbi(dp, task, &prod) == IMM_OK);
+    NEAR(prod.loglik, want_alt);
+    CHECK(imm_path_nsteps(&prod.path) == 14);
+    CHECK(imm_path_step(&prod.path, 0)->seqlen == 0);
+    CHECK(imm_path_step(&prod.path, 0)->state_id == PROTEIN_S_STATE);
+    protein_state_name(imm_path_step(&prod.path, 0)->state_id, name);
+    CHECK(strcmp(name, "S") == 0);
+    CHECK(imm_path_step(&prod.path, 13)->seqlen == 0);
+    CHECK(imm_path_step(&prod.path, 13)->state_id == PROTEIN_T_STATE);
+    protein_state_name(imm_path_step(&prod.path, 13)->state_id, name);
+    CHECK(strcmp(name, "T") == 0);
+
+    /* codons of the emitting steps */
+    struct protein_codec codec = protein_codec_init(&prof, &prod.path);
+    unsigned any = imm_abc_any_symbol_id(imm_super(nuclt));
+    struct imm_codon codon = imm_codon(nuclt, any, any, any);
+    enum rc rc;
+    unsigned i = 0;
+    while (!(rc = protein_codec_next(&codec, &seq, &codon)))
+    {
+        if (i < 10)
+        {
+            struct imm_codon want = IMM_CODON(nuclt, want_codons[i]);
+            CHECK(want.a == codon.a && want.b == codon.b && want.c == codon.c);
+        }
+        ++i;
+    }
+    CHECK(rc == RC_END);
+    CHECK(i == 10);
+
+    /* a sequence whose length disagrees with the last setup is refused, not mis-scored */
+    struct imm_seq shorter = imm_subseq(&seq, 0, 10);
+    CHECK(imm_task_setup(task, &shorter) == IMM_OK);
+    CHECK(imm_dp_viterbi(dp, task, &prod) != IMM_OK);
+
+    profile_del(&prof.super);
+    imm_prod_del(&prod);
+    imm_task_del(task);
+}
+
+/* A profile whose node k strongly prefers Met (ATG) or Trp (TGG): both have one codon only. */
+static void peaked_profile(struct protein_profile *prof, struct imm_nuclt_code const *code, char const *acc,
+                           unsigned M, unsigned phase, char *domain /* 3*M + 1 */)
+{
+    protein_profile_init(prof, acc, &imm_amino_iupac, code, PROTEIN_CFG_DEFAULT);
+    static char const amino[] = "ACDEFGHIKLMNPQRSTVWY";
+    imm_float null[20], *match = malloc(sizeof(imm_float) * 20 * M), *trans = malloc(sizeof(imm_float) * 7 * (M + 1));
+    for (int a = 0; a < 20; ++a)
+        null[a] = logf(1.0f / 20);
+    for (unsigned k = 0; k < M; ++k)
+    {
+        char fav = ((k + phase) % 3 == 0) ? 'W' : 'M';
+        for (int a = 0; a < 20; ++a)
+            match[20 * k + a] = logf(amino[a] == fav ? 0.81f : 0.01f);
+        memcpy(domain + 3 * k, fav == 'W' ? "TGG" : "ATG", 3);
+    }
+    domain[3 * M] = '\0';
+    for (unsigned i = 0; i <= M; ++i)
+    {
+        imm_float *t = trans + 7 * i; /* MM MI MD IM II DM DD */
+        t[0] = logf(0.95f), t[1] = logf(0.025f), t[2] = logf(0.025f), t[3] = logf(0.6f), t[4] = logf(0.4f);
+        t[5] = logf(0.6f), t[6] = logf(0.4f);
+        if (i == 0) t[6] = -INFINITY, t[5] = 0.0f;
+        if (i == M) t[2] = -INFINITY, t[6] = -INFINITY, t[0] = logf(0.975f), t[5] = 0.0f;
+    }
+    CHECK(protein_profile_from_params(prof, M, null, match, trans) == RC_OK);
+    free(match);
+    free(trans);
+}
+
+static void scan_threads(void)
+{
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, &imm_dna_iupac);
+    enum { NPROF = 5 };
+    struct protein_profile profs[NPROF], *ptrs[NPROF];
+    char domain[NPROF][3 * 60 + 1];
+    unsigned const sizes[NPROF] = {20, 33, 41, 57, 60};
+    for (unsigned p = 0; p < NPROF; ++p)
+    {
+        char acc[16];
+        snprintf(acc, sizeof acc, "PF%05u", p);
+        peaked_profile(&profs[p], &code, acc, sizes[p], p, domain[p]);
+        ptrs[p] = &profs[p];
+    }
+    struct protein_db db = {NPROF, ptrs};
+    struct profile_reader reader;
+    CHECK(profile_reader_setup(&reader, &db, 0) == RC_EINVAL);
+    CHECK(profile_reader_setup(&reader, &db, NUM_THREADS + 1) == RC_EINVAL);
+    CHECK(profile_reader_setup(&reader, &db, 2) == RC_OK);
+    CHECK(profile_reader_npartitions(&reader) == 2);
+    CHECK(profile_reader_partition_size(&reader, 0) == 3 && profile_reader_partition_size(&reader, 1) == 2);
+    CHECK(profile_reader_nprofiles(&reader) == NPROF);
+    struct profile *it = NULL;
+    unsigned seen = 0;
+    while (profile_reader_next(&reader, 1, &it) == RC_OK)
+    {
+        CHECK(profile_typeid(it) == PROFILE_PROTEIN);
+        CHECK(it == &profs[3 + seen].super);
+        seen++;
+    }
+    CHECK(seen == 2);
+    CHECK(profile_reader_next(&reader, 1, &it) == RC_END);
+
+    /* query 0 carries profile 3's domain between random-looking flanks; query 1 is flank only */
+    char q0[512], q1[] = "ACGTTGCAAGGCTTAACCGGTTACGATCGATTAGC";
+    snprintf(q0, sizeof q0, "ACGTTGCAAGGCTTAACC%sGGTTACGATCGATTAGC", domain[3]);
+    struct scan_thread th[2];
+    for (unsigned i = 0; i < 2; ++i)
+    {
+        thread_init(&th[i], i, &reader, true, false, 10.0);
+        thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, 77);
+    }
+    char const *queries[2] = {q0, q1};
+    for (int64_t s = 0; s < 2; ++s)
+    {
+        struct imm_seq seq = imm_seq(imm_str(queries[s]), &imm_dna_iupac.super);
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            thread_setup_seq(&th[i], &seq, 100 + s);
+            CHECK(thread_run(&th[i], (int)i) == RC_OK);
+        }
+    }
+    /* profile 3 lives in partition 1 and must be the hit for query 0; the flank-only query hits nothing */
+    CHECK(th[1].nprods >= 1);
+    CHECK(th[1].rows && strstr(th[1].rows, "77\t100\tPF00003\tdna\t") == th[1].rows);
+    if (th[1].rows)
+    {
+        CHECK(strstr(th[1].rows, "\tprotein\t0.1.0\t,S,,;") != NULL);
+        CHECK(strstr(th[1].rows, ";,T,,\n") != NULL);
+        CHECK(strstr(th[1].rows, "ATG,M") != NULL && strstr(th[1].rows, ",ATG,M") != NULL);
+        CHECK(strstr(th[1].rows, "\t101\t") == NULL); /* nothing reported for the second query */
+        /* the fragments of the match column tile the query */
+        size_t rl = strlen(th[1].rows);
+        char *row = malloc(rl + 1);
+        memcpy(row, th[1].rows, rl + 1);
+        char *nl = strchr(row, '\n');
+        if (nl) *nl = '\0';
+        char *match = strrchr(row, '\t');
+        char rebuilt[512] = "";
+        for (char *m = strtok(match + 1, ";"); m; m = strtok(NULL, ";"))
+            strncat(rebuilt, m, strcspn(m, ","));
+        CHECK(strcmp(rebuilt, q0) == 0);
+        free(row);
+    }
+    if (th[0].rows) CHECK(strstr(th[0].rows, "\t101\t") == NULL);
+    /* an empty sequence is RC_EINVAL, as protein_profile_setup reports it */
+    struct imm_seq empty = imm_seq(imm_str(""), &imm_dna_iupac.super);
+    thread_setup_seq(&th[0], &empty, 102);
+    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
+    /* a symbol outside the alphabet is rejected too */
+    struct imm_seq bad = imm_seq(imm_str("ACGTNACGT"), &imm_dna_iupac.super);
+    thread_setup_seq(&th[0], &bad, 103);
+    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
+    CHECK(strncmp(prod_header(), "scan_id\tseq_id\tprofile_name", 27) == 0);
+    for (unsigned i = 0; i < 2; ++i)
+        thread_cleanup(&th[i]);
+    for (unsigned p = 0; p < NPROF; ++p)
+        profile_del(&profs[p].super);
+}
+
+int main(void)
+{
+    golden_profile(ENTRY_DIST_UNIFORM, -55.59428153448);
+    golden_profile(ENTRY_DIST_OCCUPANCY, -54.35543421312);
+    scan_threads();
+    CHECK(xmath_partition_size(20000, 8, 7) == 2500);
+    CHECK(fabsf(xmath_lrt(-48.927f, -54.355f) - (-10.856f)) < 1e-3f);
+    if (failed) fprintf(stderr, "%d check(s) failed\n", failed);
+    else puts("test_scan_host: all checks passed");
+    return failed;
+}

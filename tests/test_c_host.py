@@ -1,0 +1,50 @@
+"""The C11 host layer (include/deciphon_host.h): builds and exports its API on CPU; its C test
+(tests/c/test_scan_host.c: the reference's protein_profile goldens + profile_reader/thread_run)
+runs on the GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "deciphon-old_amd", "host")
+HOST_SO = os.path.join(ROOT, "deciphon-old_amd", "libdeciphon_host.so")
+
+
+def build_host():
+    subprocess.check_call(["make", "-C", HOST_DIR, "-s"])
+
+
+def build_c_test(tmp_path):
+    exe = str(tmp_path / "test_scan_host")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "test_scan_host.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "deciphon-old_amd"), "-ldeciphon_host", "-ldcp_hip", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "deciphon-old_amd")])
+    return exe
+
+
+def test_host_layer_builds_and_exports_its_api(dcp, tmp_path):
+    build_host()
+    text = open(os.path.join(ROOT, "include", "deciphon_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#define[^\n]*", "", text)
+    names = set(re.findall(r"\b((?:imm|protein|profile|thread|xmath|prod)_[a-z0-9_]+)\s*\(", text))
+    lib = C.CDLL(HOST_SO)
+    names.discard("imm_state_name")  # a function TYPE (typedef), not a symbol
+    missing = sorted(n for n in names if not hasattr(lib, n))
+    assert not missing, missing
+    assert {"protein_profile_setup", "profile_reader_next", "thread_run", "imm_dp_viterbi"} <= names
+    # the reference-style C test compiles against the header (it needs a GPU to run)
+    assert os.path.exists(build_c_test(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_scan_host_on_gpu(tmp_path):
+    build_host()
+    exe = build_c_test(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout

@@ -103,7 +103,12 @@ def test_trace_reference_golden(dcp):
         nl, al = sc.scores()
         hit = np.array([(0, 0, nl[0, 0], al[0, 0])], dcp.HIT_DTYPE)
         paths, alt = sc.trace_paths(hit, True, False)
+        npaths, nscore = sc.trace_paths(hit, True, False, null_model=True)
         sc.close()
+        # null path: 11 steps, first (R,3), last (R,2)  test/protein_profile.c:43-54
+        assert nscore[0] == nl[0, 0] and abs(nscore[0] - (-48.9272687711)) <= 5e-5 * 48.93
+        assert [(int(s["state_id"]), int(s["seqlen"])) for s in (npaths[0][0], npaths[0][10])] == \
+            [((3 << 14) | 0, 3), ((3 << 14) | 0, 2)] and len(npaths[0]) == 11
         assert alt[0] == al[0, 0] and abs(alt[0] - gold) <= 5e-5 * abs(gold)
         p = paths[0]
         assert len(p) == 14  # EQ(imm_path_nsteps(&prod.path), 14) test/protein_profile.c:67
