@@ -127,8 +127,14 @@ def main():
     import torch.distributed as dist
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("DCP_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     dcp = load_product()
@@ -173,14 +179,14 @@ def main():
     def step(i):
         sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep))
         sc.sync()
-        if world > 1:
+        if world > 1 or force_dist:
             return ddist.gather_hits(hit_words, hit_count, b)
         return None
 
     def fence():
         sc.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -226,9 +232,9 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm.json")))
             if pmc.get("workload") == args.workload and pmc.get("queries_per_step") == qstep and world == 1:
-                for name, e in pmc["kernels"].items():
-                    if name.startswith(kname.split("<")[0]) and "hbm_bytes_per_launch" in e:
-                        traffic = e["hbm_bytes_per_launch"]
+                for pmc_name, pmc_entry in pmc["kernels"].items():
+                    if kname.split("<")[0] in pmc_name and "hbm_bytes_per_launch" in pmc_entry:
+                        traffic = pmc_entry["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -278,7 +284,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dcp, sizes, args.workload, qlen)
         print(json.dumps(out))
     sc.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
