@@ -28,6 +28,14 @@ namespace
 {
 constexpr int NC = DCP_NCODES;
 
+// Iteration 0 needs B0(j) = N(j) + NB in every tile.  RECOMPUTE_B: every tile re-derives N(j)
+// from the background table (12 VALU + 5 LDS gathers per row) instead of reading the B plane
+// (4 of the 28 scratch bytes per row and tile).
+#ifndef DCP_QLANE_RECOMPUTE_B
+#define DCP_QLANE_RECOMPUTE_B 1
+#endif
+constexpr bool kRecomputeB = DCP_QLANE_RECOMPUTE_B != 0;
+
 // Read-only tables are accessed through the constant address space: the data
 // never changes during the kernel, and loads at wave-uniform addresses then
 // become scalar (SMEM) loads instead of per-lane VMEM loads -- the compiler
@@ -133,7 +141,7 @@ __device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, f
         r.Xd[slot] = pXd[off];
         r.Em[slot] = pEm[off];
     }
-    if (!FIRST || !first_iter) r.B[slot] = pB[off];
+    if (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = pB[off];
 }
 
 template <int G, bool FIRST, bool LAST>
@@ -146,7 +154,7 @@ __device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float con
         unsigned const c = code_of(w, l + 1);
         in.e0[l] = *reinterpret_cast<float4 const *>(tabM + (size_t)c * 4);
         in.eI[l] = tabI[c];
-        if constexpr (FIRST || LAST) in.eN[l] = tabN[c];
+        if constexpr (FIRST || LAST || kRecomputeB) in.eN[l] = tabN[c];
     }
 }
 
@@ -195,20 +203,24 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         eN[l] = in.eN[l];
     }
 
-    if constexpr (FIRST)
+    if constexpr (FIRST || kRecomputeB)
     {
         if (first_iter)
         {
-            // N(j), R(j); B0(j) = N(j) + NB  (S(j>0) = -inf)
+            // N(j); B0(j) = N(j) + NB  (S(j>0) = -inf).  The first tile also runs the null
+            // model R(j) and publishes B0 for the (rare) later iterations.
             float const N = mx5(s.PN[s1] + eN[0], s.PN[s2] + eN[1], s.PN[s3] + eN[2],
                                 s.PN[s4] + eN[3], s.PN[s5] + eN[4]);
-            float const Rn = mx5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
-                                 s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
             s.PN[PH] = N + xt.NN;
-            s.PR[PH] = Rn + xt.RR;
-            o.Rn = at_end ? Rn : o.Rn;
             Bj = N + xt.NB;
-            pB[off] = Bj;
+            if constexpr (FIRST)
+            {
+                float const Rn = mx5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
+                                     s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
+                s.PR[PH] = Rn + xt.RR;
+                o.Rn = at_end ? Rn : o.Rn;
+                pB[off] = Bj;
+            }
         }
     }
 

@@ -329,3 +329,47 @@ def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M, kern):
         _, _, path = oprof.viterbi(1, bytes(jump))
         ndel = sum(1 for sid, _ in path if (sid >> 14) == 2)
         assert ndel >= 20
+
+
+def test_qlane_at_block_scale(dcp, oracle32, scanner):
+    """The throughput kernel with every lane in use: 700 queries (2 full 256-query blocks + a partial
+    one, lengths 1..400 so the length sort matters) x 45 profiles of mixed sizes (more tasks than a
+    few blocks take in one go).  Both device kernels must agree bit for bit on all 31 500 pairs,
+    the hit lists must be identical, and a sample of pairs is checked against the oracle."""
+    rng = np.random.default_rng(2025)
+    sizes = [int(m) for m in rng.integers(2, 330, 40)] + [600, 1100, 8, 9, 16]
+    params = [pfam_like_params(rng, M) for M in sizes]
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    oprofs = [oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01) for prm in params]
+    seqs = rand_seqs(rng, 700, 1, 400)
+    for q, p in ((5, 3), (300, 17), (699, 40), (256, 0)):  # planted hits, also at block boundaries
+        seqs[q] = planted_query(rng, oprofs[p], sizes[p], flank=12)
+    seqs[511] = np.concatenate([planted_query(rng, oprofs[7], sizes[7], 5), planted_query(rng, oprofs[7], sizes[7], 5)])
+    scanner.upload_db(profiles)
+    scanner.upload_seqs(seqs)
+    out = {}
+    for name, k in (("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE), ("auto", dcp.KERNEL_AUTO)):
+        scanner.scan(True, False, 10.0, kernel=k)
+        out[name] = scanner.scores() + (scanner.hits(),)
+    for name in ("qlane", "auto"):
+        assert same_bits(out[name][0], out["rowsweep"][0])
+        assert same_bits(out[name][1], out["rowsweep"][1])
+        assert np.array_equal(out[name][2], out["rowsweep"][2])
+    hits = out["qlane"][2]
+    got = {(int(h["seq_idx"]), int(h["profile_idx"])) for h in hits}
+    assert {(5, 3), (300, 17), (699, 40), (256, 0), (511, 7)} <= got
+    gn, ga = out["qlane"][:2]
+    assert np.isfinite(gn).all() and np.isfinite(ga).all()
+    # oracle (own model build) on a sample of pairs incl. every hit
+    sample = list(got) + [(int(rng.integers(0, 700)), int(rng.integers(0, len(sizes)))) for _ in range(60)]
+    for q, p in sample:
+        rc, nl, al = (oprofs[p].setup(len(seqs[q]), True, False), *oprofs[p].viterbi_fast(bytes(seqs[q]))[1:])
+        assert rc == 0
+        assert abs(gn[q, p] - nl) <= REL * abs(nl) and abs(ga[q, p] - al) <= REL * abs(al)
+    # a sub-range scan keeps batch indices and equals the full scan there
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE, q_range=(200, 600))
+    n2, a2 = scanner.scores()
+    assert same_bits(n2[200:600], gn[200:600]) and same_bits(a2[200:600], ga[200:600])
+    h2 = scanner.hits()
+    assert {(int(h["seq_idx"]), int(h["profile_idx"])) for h in h2} == {x for x in got if 200 <= x[0] < 600}
