@@ -56,7 +56,8 @@ ABI_SYMBOLS = [
     "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
     "dcp_gpu_last_scan_launch_info", "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
     "dcp_gpu_trace_paths", "dcp_state_name", "dcp_profile_decode", "dcp_gc_decode",
-    "dcp_prod_format_row", "dcp_prod_header",
+    "dcp_prod_format_row", "dcp_prod_header", "dcp_h3reader_open", "dcp_h3reader_next",
+    "dcp_h3reader_error", "dcp_h3reader_close", "dcp_swissprot_null_lprobs", "dcp_profile_consensus",
 ]
 
 
@@ -145,6 +146,12 @@ def _load():
         "dcp_prod_format_row": (C.c_long, [C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p,
                                            C.c_double, C.c_double, C.c_char_p, C.c_char_p, P, P, U, P, U]),
         "dcp_prod_header": (C.c_char_p, []),
+        "dcp_h3reader_open": (P, [C.c_char_p, I, F]),
+        "dcp_h3reader_next": (I, [P, C.POINTER(P)]),
+        "dcp_h3reader_error": (C.c_char_p, [P]),
+        "dcp_h3reader_close": (None, [P]),
+        "dcp_swissprot_null_lprobs": (None, [P]),
+        "dcp_profile_consensus": (C.c_char_p, [P]),
         "dcp_gpu_scan_cells": (C.c_uint64, [P]),
         "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
     }
@@ -254,6 +261,10 @@ class ProteinProfile:
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,)).reshape(shape).copy()
 
     @property
+    def consensus(self):
+        return lib.dcp_profile_consensus(self._h).decode()
+
+    @property
     def trans8(self):
         return self._view(lib.dcp_profile_trans8(self._h), (8, self.core_size))
 
@@ -284,6 +295,33 @@ def gc_decode(codon):
 
 
 PROD_HEADER = lib.dcp_prod_header().decode()
+
+
+def swissprot_null_lprobs():
+    """Swiss-Prot 50.8 background (src/model/protein_h3reader.c:79-103), log-probabilities."""
+    out = np.zeros(20, np.float32)
+    lib.dcp_swissprot_null_lprobs(out.ctypes.data)
+    return out
+
+
+def read_hmmer3(path, cfg=PROTEIN_CFG_DEFAULT):
+    """All profiles of a HMMER3 ASCII file: protein_h3reader_next + protein_profile_absorb per
+    profile, as hmm_press does (src/server/hmm.c:120-178)."""
+    r = lib.dcp_h3reader_open(str(path).encode(), cfg.entry_dist, cfg.epsilon)
+    if not r:
+        raise DcpError(RC_EIO, f"failed to open {path}")
+    out = []
+    try:
+        while True:
+            h = C.c_void_p()
+            rc = lib.dcp_h3reader_next(r, C.byref(h))
+            if rc == RC_END:
+                return out
+            if rc:
+                raise DcpError(rc, lib.dcp_h3reader_error(r).decode())
+            out.append(ProteinProfile(h.value))
+    finally:
+        lib.dcp_h3reader_close(r)
 
 
 def frame_table_host(dist, epsilon):

@@ -302,6 +302,7 @@ dcp_profile *dcp_profile_sample(char const *accession, unsigned seed,
 void dcp_profile_del(dcp_profile *p) { delete p; }
 unsigned dcp_profile_core_size(dcp_profile const *p) { return p->core_size; }
 char const *dcp_profile_accession(dcp_profile const *p) { return p->accession; }
+char const *dcp_profile_consensus(dcp_profile const *p) { return p->consensus.data(); }
 float const *dcp_profile_trans8(dcp_profile const *p) { return p->trans8.data(); }
 float const *dcp_profile_null_dist(dcp_profile const *p) { return p->null_dist; }
 float const *dcp_profile_insert_dist(dcp_profile const *p) { return p->insert_dist; }
@@ -648,6 +649,187 @@ long dcp_prod_format_row(char *buf, size_t cap, int64_t scan_id, int64_t seq_id,
     std::memcpy(buf, out.data(), out.size());
     buf[out.size()] = '\0';
     return (long)out.size();
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// HMMER3 ASCII reader
+// ---------------------------------------------------------------------------
+#include <fstream>
+#include <sstream>
+
+struct dcp_h3reader
+{
+    std::ifstream in;
+    int entry_dist;
+    float epsilon;
+    std::string err;
+    unsigned line_no = 0;
+};
+
+namespace
+{
+// one numeric field of a HMMER3 model line: -ln(p), or '*' for p = 0  ->  ln(p)
+bool h3_lprob(std::string const &tok, float *out)
+{
+    if (tok == "*")
+    {
+        *out = kNegInfF;
+        return true;
+    }
+    char *end = nullptr;
+    double v = std::strtod(tok.c_str(), &end);
+    if (end == tok.c_str() || *end != '\0' || !(v >= 0.0)) return false;
+    *out = (float)(-v);
+    if (*out == 0.0f) *out = 0.0f; // no negative zero
+    return true;
+}
+
+std::vector<std::string> h3_split(std::string const &line)
+{
+    std::vector<std::string> out;
+    std::istringstream ss(line);
+    std::string tok;
+    while (ss >> tok)
+        out.push_back(tok);
+    return out;
+}
+} // namespace
+
+extern "C" {
+
+void dcp_swissprot_null_lprobs(float out[DCP_AMINO_SIZE])
+{
+    // HMMER3's Swiss-Prot 50.8 amino-acid frequencies, alphabet order ACDEFGHIKLMNPQRSTVWY
+    static double const freq[20] = {0.0787945, 0.0151600, 0.0535222, 0.0668298, 0.0397062, 0.0695071, 0.0229198,
+                                    0.0590092, 0.0594422, 0.0963728, 0.0237718, 0.0414386, 0.0482904, 0.0395639,
+                                    0.0540978, 0.0683364, 0.0540687, 0.0673417, 0.0114135, 0.0304133};
+    for (int i = 0; i < 20; ++i)
+        out[i] = (float)std::log(freq[i]);
+}
+
+dcp_h3reader *dcp_h3reader_open(char const *path, int entry_dist, float epsilon)
+{
+    if (!path) return nullptr;
+    dcp_h3reader *r = new (std::nothrow) dcp_h3reader();
+    if (!r) return nullptr;
+    r->in.open(path);
+    if (!r->in)
+    {
+        delete r;
+        return nullptr;
+    }
+    r->entry_dist = entry_dist;
+    r->epsilon = epsilon;
+    return r;
+}
+
+char const *dcp_h3reader_error(dcp_h3reader const *r) { return r ? r->err.c_str() : "no reader"; }
+void dcp_h3reader_close(dcp_h3reader *r) { delete r; }
+
+int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
+{
+    if (!r || !out) return DCP_EINVAL;
+    *out = nullptr;
+    auto parse_error = [&](std::string const &what) {
+        r->err = "line " + std::to_string(r->line_no) + ": " + what;
+        return (int)DCP_EPARSE;
+    };
+    std::string line;
+    auto next_line = [&]() -> bool {
+        while (std::getline(r->in, line))
+        {
+            ++r->line_no;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.find_first_not_of(" \t") != std::string::npos) return true;
+        }
+        return false;
+    };
+
+    // ---- header -----------------------------------------------------------
+    if (!next_line()) return DCP_END;
+    if (line.compare(0, 6, "HMMER3") != 0) return parse_error("expected a HMMER3 header");
+    std::string name, acc, alph;
+    unsigned leng = 0;
+    bool have_leng = false;
+    for (;;)
+    {
+        if (!next_line()) return parse_error("unexpected end of file in the header");
+        std::vector<std::string> f = h3_split(line);
+        if (f[0] == "HMM") break;
+        if (f.size() >= 2)
+        {
+            if (f[0] == "NAME") name = f[1];
+            else if (f[0] == "ACC") acc = f[1];
+            else if (f[0] == "ALPH") alph = f[1];
+            else if (f[0] == "LENG")
+            {
+                char *end = nullptr;
+                long v = std::strtol(f[1].c_str(), &end, 10);
+                if (*end != '\0' || v < 0) return parse_error("bad LENG");
+                leng = (unsigned)v;
+                have_leng = true;
+            }
+        }
+    }
+    if (!have_leng) return parse_error("missing LENG");
+    if (alph != "amino") return parse_error("ALPH must be amino");
+    {
+        std::vector<std::string> f = h3_split(line); // "HMM A C D ... Y"
+        if (f.size() != 21) return parse_error("expected 20 amino-acid columns");
+        for (int i = 0; i < 20; ++i)
+            if (f[(size_t)i + 1].size() != 1 || f[(size_t)i + 1][0] != kAminoSymbols[i])
+                return parse_error("amino-acid columns are not in ACDEFGHIKLMNPQRSTVWY order");
+    }
+    if (!next_line()) return parse_error("missing the transition header line"); // m->m m->i ...
+    if (leng == 0 || leng > DCP_CORE_SIZE_MAX)
+    {
+        r->err = "core size out of range";
+        return DCP_EINVAL; // protein_model_setup: protein_model.c:157-160
+    }
+
+    std::vector<float> trans((size_t)7 * (leng + 1)), match((size_t)20 * leng);
+    std::string cons(leng, '-');
+    auto read_trans = [&](unsigned i) -> bool {
+        std::vector<std::string> f = h3_split(line);
+        if (f.size() != 7) return false;
+        for (int k = 0; k < 7; ++k) // m->m m->i m->d i->m i->i d->m d->d = MM MI MD IM II DM DD
+            if (!h3_lprob(f[(size_t)k], &trans[(size_t)7 * i + k])) return false;
+        return true;
+    };
+
+    // ---- node 0: optional COMPO line, insert emissions, transitions ---------------------------
+    if (!next_line()) return parse_error("unexpected end of file");
+    if (h3_split(line)[0] == "COMPO" && !next_line()) return parse_error("unexpected end of file");
+    if (h3_split(line).size() != 20) return parse_error("expected the insert emissions of node 0");
+    if (!next_line() || !read_trans(0)) return parse_error("bad transitions of node 0");
+
+    // ---- nodes 1..LENG -------------------------------------------------------------------------
+    for (unsigned k = 1; k <= leng; ++k)
+    {
+        if (!next_line()) return parse_error("unexpected end of file in the model");
+        std::vector<std::string> f = h3_split(line);
+        if (f.size() < 21) return parse_error("bad match line");
+        char *end = nullptr;
+        long idx = std::strtol(f[0].c_str(), &end, 10);
+        if (*end != '\0' || idx != (long)k) return parse_error("node index out of sequence");
+        for (int a = 0; a < 20; ++a)
+            if (!h3_lprob(f[(size_t)a + 1], &match[(size_t)20 * (k - 1) + a])) return parse_error("bad match emission");
+        if (f.size() >= 23 && f[22].size() == 1) cons[k - 1] = f[22][0]; // MAP CONS RF MM CS
+        if (!next_line() || h3_split(line).size() != 20) return parse_error("bad insert line");
+        if (!next_line() || !read_trans(k)) return parse_error("bad transition line");
+    }
+    if (!next_line() || h3_split(line)[0] != "//") return parse_error("expected the // terminator");
+
+    float null_lp[20];
+    dcp_swissprot_null_lprobs(null_lp);
+    int rc = DCP_OK;
+    std::string const &label = acc.empty() ? name : acc;
+    *out = dcp_profile_new(label.c_str(), leng, r->entry_dist, r->epsilon, null_lp, match.data(), trans.data(),
+                           cons.c_str(), &rc);
+    if (!*out) r->err = "profile rejected";
+    return rc;
 }
 
 } // extern "C"

@@ -102,6 +102,26 @@ void dcp_profile_del(dcp_profile *);
 unsigned dcp_profile_core_size(dcp_profile const *);
 char const *dcp_profile_accession(dcp_profile const *);
 
+/* ---- HMMER3 ASCII reader: .hmm -> profiles, what protein_h3reader_next +
+ * protein_profile_absorb do in hmm_press (src/model/protein_h3reader.c:18-72,
+ * src/server/hmm.c:120-178). The reference parses with the third-party `hmr` library (absent);
+ * this is an own parser of the published HMMER3/f text format: per profile the node-0 transition
+ * line gives trans[0]; every node line gives 20 match -ln(p) values (`*` = probability 0) and its
+ * CONS letter, the next line (insert emissions) is ignored as the reference ignores it, the third
+ * gives trans[k]. The null model is the hard-coded Swiss-Prot 50.8 amino frequencies
+ * (protein_h3reader.c:79-103); the profile's accession is the ACC field (hmm.c:113-117), NAME if
+ * there is none. */
+typedef struct dcp_h3reader dcp_h3reader;
+dcp_h3reader *dcp_h3reader_open(char const *path, int entry_dist, float epsilon);
+/* DCP_OK and *out (caller owns it), DCP_END at end of file, DCP_EPARSE on malformed input
+ * (message in dcp_h3reader_error), DCP_EINVAL for core sizes outside 1..4096. */
+int dcp_h3reader_next(dcp_h3reader *, dcp_profile **out);
+char const *dcp_h3reader_error(dcp_h3reader const *);
+void dcp_h3reader_close(dcp_h3reader *);
+/* log of the Swiss-Prot 50.8 background frequencies, imm_amino_iupac order */
+void dcp_swissprot_null_lprobs(float out[DCP_AMINO_SIZE]);
+char const *dcp_profile_consensus(dcp_profile const *);
+
 /* Read-only views (host memory owned by the profile):
  *   trans8 [8][core_size]: rows entry(B->Mk), MM, IM, DM, MD, DD (edges INTO
  *   node k from node k-1) and MI, II (node k's own insert edges);
