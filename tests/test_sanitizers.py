@@ -1,0 +1,34 @@
+"""ASan + UBSan on the CPU builds (upstream's CI runs its tests under both:
+.github/workflows/test.yml:27).  GPU AddressSanitizer is not available on this pool, so the device
+code is covered by bit-exact parity instead."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_under_asan_ubsan():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "check-asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("oracle selftest ok") == 2
+
+
+def test_host_model_under_asan_ubsan(tmp_path):
+    from test_h3reader import random_model, write_hmm
+
+    rng = np.random.default_rng(4)
+    good, bad = tmp_path / "two.hmm", tmp_path / "bad.hmm"
+    write_hmm(good, [("a", "PF1.1", *random_model(rng, 3)), ("b", "", *random_model(rng, 40))])
+    bad.write_text(good.read_text().replace("ALPH  amino", "ALPH  RNA"))
+    exe = str(tmp_path / "asan_host_model")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "deciphon-old_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "asan_host_model.cpp"),
+                           os.path.join(ROOT, "deciphon-old_amd", "csrc", "dcp_model.cpp"), "-o", exe])
+    r = subprocess.run([exe, str(good), str(bad)], capture_output=True, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "asan_host_model ok" in r.stdout
