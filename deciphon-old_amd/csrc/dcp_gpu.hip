@@ -671,6 +671,14 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         if (f && !strcmp(f, "rowsweep")) kernel = 1;
         else if (f && !strcmp(f, "qlane")) kernel = 2;
         else kernel = nq >= 128 ? 2 : 1;
+        // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
+        if (kernel == 2)
+        {
+            unsigned lmax = 0;
+            for (unsigned q = q_begin; q < q_end; ++q)
+                lmax = std::max(lmax, c->seq_len[q]);
+            if (lmax > 200000u) kernel = 1;
+        }
     }
     c->last_kernel = kernel;
     if (kernel == 2)
@@ -735,8 +743,15 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
-        unsigned const nblocks = (unsigned)std::min<uint64_t>(ntasks, 2ull * c->num_cus);
-        size_t const need = (size_t)nblocks * 4u * ((size_t)qa.lmax + 8u) * NT; // planes of lmax+8 rows
+        // scratch = 4 planes x (lmax + 8) rows x NT floats per resident block; long sequences
+        // (SCHED_SEQ_SIZE allows 1 MiB) get fewer resident blocks so the planes stay within budget
+        uint64_t const per_block = 4ull * ((uint64_t)qa.lmax + 8u) * NT; // floats
+        uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
+        uint64_t fit = per_block ? budget / per_block : 0;
+        unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, 2ull * c->num_cus), fit);
+        if (nblocks == 0)
+            return c->fail(DCP_ENOMEM, "sequence of %u nt is too long for the query-lane kernel: use kernel = 1", qa.lmax);
+        size_t const need = (size_t)nblocks * per_block;
         if (c->d_scratch.n < need) HIP_TRY(c, c->d_scratch.alloc(need));
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));

@@ -130,18 +130,18 @@ struct Ring
     float B[5], Xm[5], Xd[5], Em[5];
 };
 
-template <bool FIRST>
+template <bool FIRST, bool FI>
 __device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, float const *pXm,
-                                           float const *pXd, float const *pEm, unsigned off,
-                                           bool first_iter)
+                                           float const *pXd, float const *pEm, unsigned off)
 {
+    constexpr bool first_iter = FI;
     if constexpr (!FIRST)
     {
         r.Xm[slot] = pXm[off];
         r.Xd[slot] = pXd[off];
         r.Em[slot] = pEm[off];
     }
-    if (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = pB[off];
+    if constexpr (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = pB[off];
 }
 
 template <int G, bool FIRST, bool LAST>
@@ -166,14 +166,14 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
+template <int G, bool FIRST, bool LAST, bool FI, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float const *tabI, float const *tabN, unsigned w,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned off, LaneXt const &xt,
-                                       bool first_iter, bool live, bool at_end, bool &dirty,
-                                       SweepOut &o)
+                                       bool live, bool at_end, bool &dirty, SweepOut &o)
 {
+    constexpr bool first_iter = FI; // compile time: no branch inside the row body
     constexpr int KT = 4 * G;
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;
     float const ni = ninf();
@@ -194,7 +194,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         E = ring.Em[PH];
     }
     // fetch row j+D into its slot (slot PH itself when D == 5: it is consumed above)
-    ring_fetch<FIRST>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT), first_iter);
+    ring_fetch<FIRST, FI>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT));
     float eI[5], eN[5];
 #pragma unroll
     for (int l = 0; l < 5; ++l)
@@ -205,7 +205,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
     if constexpr (FIRST || kRecomputeB)
     {
-        if (first_iter)
+        if constexpr (first_iter)
         {
             // N(j); B0(j) = N(j) + NB  (S(j>0) = -inf).  The first tile also runs the null
             // model R(j) and publishes B0 for the (rare) later iterations.
@@ -295,13 +295,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST, int NT, int D>
+template <int G, bool FIRST, bool LAST, bool FI, int NT, int D>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float const *tabI,
                                          float const *tabN, uint32_t const *__restrict__ words,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
-                                         size_t plane, unsigned tid, LaneXt const &xt,
-                                         bool first_iter, bool &dirty, SweepOut &o,
-                                         unsigned wmask, unsigned rowstep)
+                                         size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
+                                         SweepOut &o, unsigned wmask, unsigned rowstep)
 {
     constexpr int KT = 4 * G;
     float const ni = ninf();
@@ -351,13 +350,13 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
     ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, w);
 #pragma unroll
     for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
-        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT), first_iter);
+        ring_fetch<FIRST, FI>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT));
 
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
-        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm, pXd, \
-                                   pEm, off, xt, first_iter, active && j <= L,             \
-                                   active && j == L, dirty, o);                            \
+        ql_row<G, FIRST, LAST, FI, PH, NT, D>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm,  \
+                                   pXd, pEm, off, xt, active && j <= L, active && j == L,  \
+                                   dirty, o);                                              \
         /* advance the window: base of row j+2 sits at position j+1; sequence words */     \
         /* are fetched one word (16 rows) ahead, clamped to the lane's own sequence */     \
         unsigned const pos = j + 1u;                                                       \
@@ -468,14 +467,24 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
                 if (Lwave == 0u) continue; // no lane of this wavefront has work
                 cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
                 bool const first = t == 0, last = t + 1 == T;
-                if (first && last)
-                    ql_sweep<G, true, true, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
-                else if (first)
-                    ql_sweep<G, true, false, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
-                else if (last)
-                    ql_sweep<G, false, true, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
+#define QL_SWEEP(F, L_, FI_)                                                                     \
+    ql_sweep<G, F, L_, FI_, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, \
+                                   xt, dirty, o, a.dbg_wmask, a.dbg_rowstep)
+                if (first_iter)
+                {
+                    if (first && last) QL_SWEEP(true, true, true);
+                    else if (first) QL_SWEEP(true, false, true);
+                    else if (last) QL_SWEEP(false, true, true);
+                    else QL_SWEEP(false, false, true);
+                }
                 else
-                    ql_sweep<G, false, false, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, xt, first_iter, dirty, o, a.dbg_wmask, a.dbg_rowstep);
+                {
+                    if (first && last) QL_SWEEP(true, true, false);
+                    else if (first) QL_SWEEP(true, false, false);
+                    else if (last) QL_SWEEP(false, true, false);
+                    else QL_SWEEP(false, false, false);
+                }
+#undef QL_SWEEP
             }
             first_iter = false;
             if (!__syncthreads_or(dirty ? 1 : 0)) break;

@@ -373,3 +373,20 @@ def test_qlane_at_block_scale(dcp, oracle32, scanner):
     assert same_bits(n2[200:600], gn[200:600]) and same_bits(a2[200:600], ga[200:600])
     h2 = scanner.hits()
     assert {(int(h["seq_idx"]), int(h["profile_idx"])) for h in h2} == {x for x in got if 200 <= x[0] < 600}
+
+
+def test_long_sequences(dcp, oracle32, scanner, kern):
+    """Queries up to 10 kbp (BASELINE config C5's upper end) and one far beyond: offsets, scratch planes
+    and the sequence look-ahead hold; scores equal the oracle's bit for bit on the product's tables."""
+    rng = np.random.default_rng(77)
+    profiles = make_profiles(dcp, [(201, 50, ENTRY_DIST_OCCUPANCY, 0.01), (202, 300, ENTRY_DIST_OCCUPANCY, 0.01),
+                                   (203, 700, ENTRY_DIST_UNIFORM, 0.01)])
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (4095, 7000, 10000, 15, 16, 17, 31, 32, 33, 25000)]
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0, kernel=kern)
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    assert same_bits(gn, on)
+    assert same_bits(ga, oa)
+    assert np.isfinite(ga).all()
