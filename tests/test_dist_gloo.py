@@ -80,3 +80,63 @@ def test_shard_and_gather_world2(tmp_path):
     port = 29500 + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _gpu_worker(rank, world, port, tmpdir):
+    """Two ranks share the one GPU of the test box: each holds its shard of the DB resident, scans
+    ALL queries, and the hit records are all-gathered (gloo here, RCCL in bench.py)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_product
+
+    dcp = load_product()
+    from deciphon_old_amd import dist as ddist
+    import test_gpu_parity as tp
+    from oracle_py import Oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        sizes = [int(m) for m in rng.integers(20, 200, 24)]
+        params = [tp.pfam_like_params(rng, M) for M in sizes]
+        cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+        orc = Oracle(32)
+        seqs = tp.rand_seqs(rng, 150, 30, 200)
+        for q, p in ((3, 2), (77, 13), (149, 23), (20, 12)):
+            seqs[q] = tp.planted_query(rng, orc.new(*params[p], 2, 0.01), sizes[p], flank=10)
+        b, e = ddist.shard_range(sizes, world, rank)
+        sc = dcp.Scanner(0)
+        sc.upload_db([dcp.ProteinProfile.from_params(*params[p], cfg) for p in range(b, e)])
+        sc.upload_seqs(seqs)
+        sc.scan(True, False, 10.0)
+        mine = sc.hits()
+        nl, al = sc.scores()
+        cap = 256
+        words = torch.zeros((cap, 4), dtype=torch.int32)
+        if len(mine):
+            words[:len(mine)] = torch.from_numpy(mine.view(np.int32).reshape(len(mine), 4).copy())
+        allh = ddist.gather_hits(words, torch.tensor([len(mine)], dtype=torch.int32), b)
+        sc.close()
+        got = {(int(h["seq_idx"]), int(h["profile_idx"])) for h in allh}
+        assert {(3, 2), (77, 13), (149, 23), (20, 12)} <= got
+        if rank == 0:  # the unsharded scan gives the same hit list, record for record
+            full = dcp.Scanner(0)
+            full.upload_db([dcp.ProteinProfile.from_params(*prm, cfg) for prm in params])
+            full.upload_seqs(seqs)
+            full.scan(True, False, 10.0)
+            want = full.hits()
+            fn, fa = full.scores()
+            full.close()
+            assert np.array_equal(allh, want)
+            assert np.array_equal(fn[:, b:e], nl) and np.array_equal(fa[:, b:e], al)
+        open(os.path.join(tmpdir, f"gpu_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_scan_two_ranks_one_gpu(tmp_path):
+    world = 2
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"gpu_ok{r}").exists() for r in range(world))
