@@ -104,6 +104,30 @@ def cpu_baseline(dcp, sizes, workload, qlen, budget_s=15.0):
                       f"OpenMP schedule(static,1) over {threads} count-balanced partitions, {dt:.1f} s"}
 
 
+def parity_sample(dcp, sc, sizes, shard_begin, qlen, q_range, nsample=48):
+    """Outside the timed region: re-scan a few queries of the benchmarked batch keeping dense scores and
+    compare a random sample of (query, profile) pairs with the CPU oracle on the same synthetic inputs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_py import Oracle  # checker only
+
+    orc = Oracle(32)
+    q0, q1 = q_range[0], min(q_range[1], q_range[0] + 8)
+    sc.scan(True, False, 10.0, keep_scores=True, sync=True, q_range=(q0, q1))
+    nl, al = sc.scores()
+    rng = np.random.default_rng(12345)
+    worst, n = 0.0, 0
+    queries = {q: bytes(make_queries(q, q + 1, qlen)[0]) for q in range(q0, q1)}
+    for _ in range(nsample):
+        q = int(rng.integers(q0, q1))
+        p = int(rng.integers(0, sc.nprofiles))
+        op = orc.sample(0xDEC1F0 + shard_begin + p, int(sizes[shard_begin + p]))
+        op.setup(len(queries[q]), True, False)
+        _, on, oa = op.viterbi_fast(queries[q])
+        worst = max(worst, abs(nl[q, p] - on) / abs(on), abs(al[q, p] - oa) / abs(oa))
+        n += 1
+    return {"pairs": n, "max_rel_err_vs_oracle": float("%.3g" % worst), "tolerance": 5e-5, "ok": bool(worst <= 5e-5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,6 +306,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and qlen:
             out["cpu_baseline"] = cpu_baseline(dcp, sizes, args.workload, qlen)
+            out["parity_check"] = parity_sample(dcp, sc, sizes, b, qlen, (args.warmup * qstep, (args.warmup + 1) * qstep))
         print(json.dumps(out))
     sc.close()
     if world > 1 or force_dist:
