@@ -492,15 +492,10 @@ static enum rc rows_reserve(struct scan_thread *t, size_t extra)
     return RC_OK;
 }
 
-enum rc thread_run(struct scan_thread *t, int tid)
+static enum rc thread_prepare(struct scan_thread *t, int tid)
 {
     struct profile_reader *reader = t->reader;
-    struct imm_seq const *seq = t->seq;
-    if (!reader || !seq) return fail(RC_EINVAL, "thread has no reader or sequence");
-    unsigned const first = reader->partition_begin[t->id];
     unsigned const n = reader->partition_size[t->id];
-    if (n == 0) return RC_OK;
-
     if (!t->gpu)
     {
         int ndev = dcp_gpu_device_count();
@@ -525,53 +520,97 @@ enum rc thread_run(struct scan_thread *t, int tid)
         if (rc) return rc;
         t->db_resident = true;
     }
+    return RC_OK;
+}
 
-    /* protein_profile_setup(pp, size, ...) for every profile: rejects the empty sequence (:112) */
-    if (seq->size == 0) return fail(RC_EINVAL, "sequence cannot be empty");
-    uint32_t off[2] = {0, seq->size};
-    int drc = dcp_gpu_seqs_upload_text(t->gpu, seq->str, off, 1);
-    if (drc) return fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
+enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
+                         unsigned nseqs)
+{
+    struct profile_reader *reader = t->reader;
+    if (!reader || !seqs || nseqs == 0) return fail(RC_EINVAL, "thread has no reader or sequence");
+    unsigned const first = reader->partition_begin[t->id];
+    unsigned const n = reader->partition_size[t->id];
+    if (n == 0) return RC_OK;
+    enum rc rc = thread_prepare(t, tid);
+    if (rc) return rc;
+
+    /* protein_profile_setup(pp, size, ...) for every profile rejects the empty sequence (:112) */
+    size_t total = 0;
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        if (seqs[q].size == 0) return fail(RC_EINVAL, "sequence cannot be empty");
+        total += seqs[q].size;
+    }
+    /* the caller's buffers may be overwritten by the next fetch (scan.c:227-229): copy now */
+    char *text = malloc(total + 1);
+    uint32_t *off = malloc(((size_t)nseqs + 1) * sizeof *off);
+    if (!text || !off)
+    {
+        free(text), free(off);
+        return fail(RC_ENOMEM, "alloc sequence batch");
+    }
+    off[0] = 0;
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        memcpy(text + off[q], seqs[q].str, seqs[q].size);
+        off[q + 1] = off[q] + seqs[q].size;
+    }
+    int drc = dcp_gpu_seqs_upload_text(t->gpu, text, off, nseqs);
+    if (drc) rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
     struct dcp_scan_params prm = {t->multi_hits, t->hmmer3_compat, (float)t->lrt_threshold, 0, 0};
-    if ((drc = dcp_gpu_scan(t->gpu, &prm)) || (drc = dcp_gpu_sync(t->gpu)))
-        return fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
+    if (!rc && ((drc = dcp_gpu_scan(t->gpu, &prm)) || (drc = dcp_gpu_sync(t->gpu))))
+        rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
 
-    /* lrt filter ran on the device (scan_thread.c:121-123): only hits come back */
+    /* lrt filter ran on the device (scan_thread.c:121-123): only hits come back, sorted by (seq, profile) */
     unsigned nhits = 0;
-    struct dcp_hit *hits = malloc((size_t)n * sizeof *hits);
-    if (!hits) return fail(RC_ENOMEM, "alloc hits");
-    enum rc rc = RC_OK;
-    if ((drc = dcp_gpu_fetch_hits(t->gpu, hits, n, &nhits))) rc = fail((enum rc)drc, "fetch hits");
+    size_t hit_cap = (size_t)n * nseqs;
+    struct dcp_hit *hits = NULL;
     struct dcp_step *steps = NULL;
     uint32_t *soff = NULL;
     uint8_t *ids = NULL;
+    if (!rc)
+    {
+        drc = dcp_gpu_fetch_hits(t->gpu, NULL, 0, &nhits); /* count first */
+        if (drc && drc != DCP_ENOMEM) rc = fail((enum rc)drc, "fetch hits");
+        if (!rc && nhits > hit_cap) rc = fail(RC_EFAIL, "more hits than pairs");
+    }
     if (!rc && nhits)
     {
+        hits = malloc((size_t)nhits * sizeof *hits);
+        if (!hits) rc = fail(RC_ENOMEM, "alloc hits");
+        if (!rc && (drc = dcp_gpu_fetch_hits(t->gpu, hits, nhits, &nhits))) rc = fail((enum rc)drc, "fetch hits");
         size_t cap = 0;
-        for (unsigned h = 0; h < nhits; ++h)
-            cap += 2 * (size_t)seq->size + 2 * (size_t)reader->db->profiles[first + hits[h].profile_idx]->core_size + 16;
-        steps = malloc(cap * sizeof *steps);
-        soff = malloc(((size_t)nhits + 1) * sizeof *soff);
-        ids = malloc(seq->size);
-        if (!steps || !soff || !ids) rc = fail(RC_ENOMEM, "alloc paths");
+        for (unsigned h = 0; !rc && h < nhits; ++h)
+            cap += 2 * (size_t)seqs[hits[h].seq_idx].size +
+                   2 * (size_t)reader->db->profiles[first + hits[h].profile_idx]->core_size + 16;
+        if (!rc)
+        {
+            steps = malloc(cap * sizeof *steps);
+            soff = malloc(((size_t)nhits + 1) * sizeof *soff);
+            ids = malloc(total);
+            if (!steps || !soff || !ids) rc = fail(RC_ENOMEM, "alloc paths");
+        }
         if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, hits, nhits, t->multi_hits, t->hmmer3_compat, 0, steps,
                                               (unsigned)cap, soff, NULL)))
             rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
-        for (unsigned i = 0; !rc && i < seq->size; ++i)
-            ids[i] = (uint8_t)symbol_id(seq->abc, seq->str[i]);
+        for (size_t i = 0; !rc && i < total; ++i)
+            ids[i] = (uint8_t)symbol_id(seqs[0].abc, text[i]);
         for (unsigned h = 0; !rc && h < nhits; ++h)
         {
+            unsigned const q = hits[h].seq_idx;
             struct protein_profile const *pp = reader->db->profiles[first + hits[h].profile_idx];
             /* strcpy(t->prod.profile_name, prof->accession); match_setup; write_product (:125-128) */
             snprintf(t->prod.profile_name, sizeof t->prod.profile_name, "%s", pp->super.accession);
+            t->prod.seq_id = seq_ids ? seq_ids[q] : t->prod.seq_id;
             t->prod.null_loglik = (double)hits[h].null_loglik;
             t->prod.alt_loglik = (double)hits[h].alt_loglik;
             unsigned ns = soff[h + 1] - soff[h];
-            size_t need = 512 + 64 * ((size_t)ns + 1) + 2 * (size_t)seq->size;
+            size_t need = 512 + 64 * ((size_t)ns + 1) + 2 * (size_t)seqs[q].size;
             if ((rc = rows_reserve(t, need))) break;
             long w = dcp_prod_format_row(t->rows + t->rows_len, t->rows_cap - t->rows_len, t->prod.scan_id,
                                          t->prod.seq_id, t->prod.profile_name, t->prod.abc_name, t->prod.alt_loglik,
-                                         t->prod.null_loglik, t->prod.profile_typeid, t->prod.version, pp->impl, ids,
-                                         seq->size, steps + soff[h], ns);
+                                         t->prod.null_loglik, t->prod.profile_typeid, t->prod.version, pp->impl,
+                                         ids + off[q], seqs[q].size, steps + soff[h], ns);
             if (w < 0)
             {
                 rc = fail(RC_EIO, "failed to write prod");
@@ -585,6 +624,72 @@ enum rc thread_run(struct scan_thread *t, int tid)
     free(soff);
     free(steps);
     free(hits);
+    free(off);
+    free(text);
+    return rc;
+}
+
+enum rc thread_run(struct scan_thread *t, int tid)
+{
+    if (!t->reader || !t->seq) return fail(RC_EINVAL, "thread has no reader or sequence");
+    int64_t id = t->prod.seq_id;
+    return thread_run_batch(t, tid, t->seq, &id, 1);
+}
+
+enum rc scan_run_local(struct protein_db const *db, struct scan_seq const *seqs, unsigned nseqs,
+                       unsigned num_threads, bool multi_hits, bool hmmer3_compat, double lrt_threshold,
+                       int64_t scan_id, unsigned batch, FILE *prods)
+{
+    if (!db || !seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
+    struct profile_reader reader;
+    enum rc rc = profile_reader_setup(&reader, db, num_threads); /* prepare_readers: scan.c:45-74 */
+    if (rc) return rc;
+    unsigned const nparts = profile_reader_npartitions(&reader);
+    struct scan_thread *th = calloc(nparts, sizeof *th);
+    struct imm_seq *bseq = malloc((size_t)batch * sizeof *bseq);
+    int64_t *bid = malloc((size_t)batch * sizeof *bid);
+    if (!th || !bseq || !bid)
+    {
+        free(th), free(bseq), free(bid);
+        return fail(RC_ENOMEM, "alloc scan");
+    }
+    for (unsigned i = 0; i < nparts; ++i)
+    {
+        thread_init(&th[i], i, &reader, multi_hits, hmmer3_compat, lrt_threshold);
+        thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, scan_id);
+    }
+    for (unsigned b0 = 0; b0 < nseqs && !rc; b0 += batch)
+    {
+        unsigned const nb = nseqs - b0 < batch ? nseqs - b0 : batch;
+        for (unsigned q = 0; q < nb; ++q)
+        {
+            bseq[q] = imm_seq(imm_str(seqs[b0 + q].data), &imm_dna_iupac.super);
+            bid[q] = seqs[b0 + q].id;
+        }
+        enum rc shared = RC_OK;
+#pragma omp parallel for schedule(static, 1)
+        for (unsigned i = 0; i < nparts; ++i)
+        {
+            enum rc r = thread_run_batch(&th[i], (int)i, bseq, bid, nb);
+            if (r)
+            {
+#pragma omp atomic write
+                shared = r; /* scan.c:246-248: first failing partition fails the scan */
+            }
+        }
+        rc = shared;
+    }
+    if (!rc)
+    {
+        /* prod_fclose: header, then every thread's rows in thread order (prod.c:119-134) */
+        if (fputs(prod_header(), prods) < 0) rc = fail(RC_EIO, "fail to finish product");
+        for (unsigned i = 0; !rc && i < nparts; ++i)
+            if (th[i].rows_len && fwrite(th[i].rows, 1, th[i].rows_len, prods) != th[i].rows_len)
+                rc = fail(RC_EIO, "fail to finish product");
+    }
+    for (unsigned i = 0; i < nparts; ++i)
+        thread_cleanup(&th[i]);
+    free(th), free(bseq), free(bid);
     return rc;
 }
 

@@ -350,7 +350,25 @@ void thread_setup_seq(struct scan_thread *t, struct imm_seq *seq, int64_t seq_id
  * filter, and for each hit the alt path and its product row (src/server/scan_thread.c:86-135).
  * tid selects the HIP device (tid % device count). */
 enum rc thread_run(struct scan_thread *t, int tid);
+/* The same for a batch of `nseqs` prefetched sequences in ONE device pass: the
+ * reference fetches and scans one sequence at a time (src/server/scan.c:227-258), which cannot fill
+ * a GPU. Products come out ordered by (sequence, profile). seq_ids[i] is the id of seqs[i]. */
+enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
+                         unsigned nseqs);
 void thread_cleanup(struct scan_thread *t);
+
+/* scan_run without the scheduler (src/server/scan.c:215-269): the sequences come from the caller instead of
+ * api_scan_next_seq, the products file is written to `prods` (header + every thread's rows, thread by
+ * thread, as prod_fclose concatenates them: src/server/prod.c:106-145). num_threads partitions = host
+ * threads (OpenMP, schedule(static,1): scan.c:239) = device contexts; `batch` sequences per device pass. */
+struct scan_seq
+{
+    int64_t id;
+    char const *data;
+};
+enum rc scan_run_local(struct protein_db const *db, struct scan_seq const *seqs, unsigned nseqs,
+                       unsigned num_threads, bool multi_hits, bool hmmer3_compat, double lrt_threshold,
+                       int64_t scan_id, unsigned batch, FILE *prods);
 /* Header line of the products file (src/server/prod.c:119-121). */
 char const *prod_header(void);
 

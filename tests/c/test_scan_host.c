@@ -226,11 +226,104 @@ static void scan_threads(void)
         profile_del(&profs[p].super);
 }
 
+/* scan_run_local (batched dispatch, 2 partitions) must write the rows per-sequence thread_run writes */
+static int cmp_str(void const *a, void const *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
+
+static unsigned split_lines(char *text, char **lines, unsigned cap)
+{
+    unsigned n = 0;
+    for (char *l = strtok(text, "\n"); l && n < cap; l = strtok(NULL, "\n"))
+        lines[n++] = l;
+    qsort(lines, n, sizeof *lines, cmp_str);
+    return n;
+}
+
+static void scan_run_batched(void)
+{
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, &imm_dna_iupac);
+    enum { NPROF = 5, NSEQ = 7 };
+    struct protein_profile profs[NPROF], *ptrs[NPROF];
+    char domain[NPROF][3 * 60 + 1];
+    unsigned const sizes[NPROF] = {20, 33, 41, 57, 60};
+    for (unsigned p = 0; p < NPROF; ++p)
+    {
+        char acc[16];
+        snprintf(acc, sizeof acc, "PF%05u", p);
+        peaked_profile(&profs[p], &code, acc, sizes[p], p, domain[p]);
+        ptrs[p] = &profs[p];
+    }
+    struct protein_db db = {NPROF, ptrs};
+    char text[NSEQ][512];
+    char const *flank[NSEQ] = {"ACGTTGCAAGGCTTAACC", "TTGACCA", "GGGCATCATCAGGAC", "A", "CCGTA", "GATTACAGATTACA", "TGCATGCAAT"};
+    struct scan_seq seqs[NSEQ];
+    for (unsigned q = 0; q < NSEQ; ++q)
+    {
+        char const *dom = q == 0 ? domain[3] : q == 5 ? domain[1] : q == 6 ? domain[4] : "";
+        snprintf(text[q], sizeof text[q], "%s%s%s", flank[q], dom, flank[(q + 3) % NSEQ]);
+        seqs[q] = (struct scan_seq){1000 + q, text[q]};
+    }
+    FILE *fp = tmpfile();
+    CHECK(fp != NULL);
+    CHECK(scan_run_local(&db, seqs, NSEQ, 2, true, false, 10.0, 9, 3, fp) == RC_OK);
+    long len = ftell(fp);
+    rewind(fp);
+    char *got = calloc((size_t)len + 1, 1);
+    CHECK(fread(got, 1, (size_t)len, fp) == (size_t)len);
+    fclose(fp);
+    CHECK(strncmp(got, prod_header(), strlen(prod_header())) == 0);
+
+    /* reference flow: one sequence at a time through thread_run, per partition */
+    struct profile_reader reader;
+    CHECK(profile_reader_setup(&reader, &db, 2) == RC_OK);
+    struct scan_thread th[2];
+    for (unsigned i = 0; i < 2; ++i)
+    {
+        thread_init(&th[i], i, &reader, true, false, 10.0);
+        thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, 9);
+    }
+    for (unsigned q = 0; q < NSEQ; ++q)
+    {
+        struct imm_seq seq = imm_seq(imm_str(text[q]), &imm_dna_iupac.super);
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            thread_setup_seq(&th[i], &seq, seqs[q].id);
+            CHECK(thread_run(&th[i], (int)i) == RC_OK);
+        }
+    }
+    size_t wl = th[0].rows_len + th[1].rows_len;
+    char *want = calloc(wl + 1, 1);
+    if (th[0].rows) memcpy(want, th[0].rows, th[0].rows_len);
+    if (th[1].rows) memcpy(want + th[0].rows_len, th[1].rows, th[1].rows_len);
+    char *gl[64], *wlines[64];
+    unsigned ng = split_lines(got + strlen(prod_header()), gl, 64), nw = split_lines(want, wlines, 64);
+    CHECK(ng == nw && ng >= 3);
+    for (unsigned i = 0; i < ng && i < nw; ++i)
+        CHECK(strcmp(gl[i], wlines[i]) == 0);
+    unsigned found = 0;
+    for (unsigned i = 0; i < ng; ++i)
+        found += strstr(gl[i], "9\t1000\tPF00003\t") == gl[i] || strstr(gl[i], "9\t1005\tPF00001\t") == gl[i] ||
+                 strstr(gl[i], "9\t1006\tPF00004\t") == gl[i];
+    CHECK(found == 3);
+    /* error propagation: an empty sequence fails the whole scan with RC_EINVAL */
+    struct scan_seq bad[2] = {{1, "ACGTACGTACGT"}, {2, ""}};
+    fp = tmpfile();
+    CHECK(scan_run_local(&db, bad, 2, 2, true, false, 10.0, 9, 2, fp) == RC_EINVAL);
+    fclose(fp);
+    free(got);
+    free(want);
+    for (unsigned i = 0; i < 2; ++i)
+        thread_cleanup(&th[i]);
+    for (unsigned p = 0; p < NPROF; ++p)
+        profile_del(&profs[p].super);
+}
+
 int main(void)
 {
     golden_profile(ENTRY_DIST_UNIFORM, -55.59428153448);
     golden_profile(ENTRY_DIST_OCCUPANCY, -54.35543421312);
     scan_threads();
+    scan_run_batched();
     CHECK(xmath_partition_size(20000, 8, 7) == 2500);
     CHECK(fabsf(xmath_lrt(-48.927f, -54.355f) - (-10.856f)) < 1e-3f);
     if (failed) fprintf(stderr, "%d check(s) failed\n", failed);

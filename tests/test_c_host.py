@@ -21,7 +21,7 @@ def build_c_test(tmp_path):
     exe = str(tmp_path / "test_scan_host")
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "test_scan_host.c"), "-o", exe,
-                           "-L", os.path.join(ROOT, "deciphon-old_amd"), "-ldeciphon_host", "-ldcp_hip", "-lm",
+                           "-L", os.path.join(ROOT, "deciphon-old_amd"), "-ldeciphon_host", "-ldcp_hip", "-lm", "-fopenmp",
                            "-Wl,-rpath," + os.path.join(ROOT, "deciphon-old_amd")])
     return exe
 
