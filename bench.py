@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--nprof", type=int, default=0, help="override profile count (debug)")
     ap.add_argument("--qstep", type=int, default=0, help="override queries per step per GPU (debug)")
+    ap.add_argument("--qlen", type=int, default=0, help="override query length (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,7 +167,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     nprof = args.nprof or wl["nprof"]
-    qlen = wl["qlen"]
+    qlen = args.qlen or wl["qlen"]
     qstep = (args.qstep or wl["qstep"]) * world
     sizes = core_sizes_for(args.workload, nprof)
 

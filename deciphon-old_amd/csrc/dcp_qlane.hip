@@ -125,6 +125,17 @@ struct RowIn
 // ahead into a register ring indexed by j % 5: a row's compute time (~0.6 us) is
 // shorter than loaded-HBM latency, and with two waves per SIMD a late load stalls
 // the SIMD.
+// scratch plane access: wave-uniform base pointer + 32-bit BYTE offset, the form that maps to
+// global_load/store with an SGPR base and a VGPR offset (no 64-bit address arithmetic per access)
+__device__ __forceinline__ float ld_off(float const *base, unsigned boff)
+{
+    return *reinterpret_cast<float const *>(reinterpret_cast<char const *>(base) + boff);
+}
+__device__ __forceinline__ void st_off(float *base, unsigned boff, float v)
+{
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + boff) = v;
+}
+
 struct Ring
 {
     float B[5], Xm[5], Xd[5], Em[5];
@@ -137,24 +148,25 @@ __device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, f
     constexpr bool first_iter = FI;
     if constexpr (!FIRST)
     {
-        r.Xm[slot] = pXm[off];
-        r.Xd[slot] = pXd[off];
-        r.Em[slot] = pEm[off];
+        r.Xm[slot] = ld_off(pXm, off);
+        r.Xd[slot] = ld_off(pXd, off);
+        r.Em[slot] = ld_off(pEm, off);
     }
-    if constexpr (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = pB[off];
+    if constexpr (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = ld_off(pB, off);
 }
 
 template <int G, bool FIRST, bool LAST>
-__device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float const *tabI,
-                                         float const *tabN, unsigned w)
+__device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float2 const *tabIN, unsigned w)
 {
 #pragma unroll
     for (int l = 0; l < 5; ++l)
     {
         unsigned const c = code_of(w, l + 1);
         in.e0[l] = *reinterpret_cast<float4 const *>(tabM + (size_t)c * 4);
-        in.eI[l] = tabI[c];
-        if constexpr (FIRST || LAST || kRecomputeB) in.eN[l] = tabN[c];
+        // insert and background emissions of a word sit side by side: one ds_read_b64
+        float2 const v = tabIN[c];
+        in.eI[l] = v.x;
+        in.eN[l] = v.y;
     }
 }
 
@@ -168,7 +180,7 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // wn) as soon as group 0 has consumed it.
 template <int G, bool FIRST, bool LAST, bool FI, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
-                                       float const *tabI, float const *tabN, unsigned w,
+                                       float2 const *tabIN, unsigned w,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned off, LaneXt const &xt,
                                        bool live, bool at_end, bool &dirty, SweepOut &o)
@@ -194,7 +206,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         E = ring.Em[PH];
     }
     // fetch row j+D into its slot (slot PH itself when D == 5: it is consumed above)
-    ring_fetch<FIRST, FI>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT));
+    ring_fetch<FIRST, FI>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT * 4));
     float eI[5], eN[5];
 #pragma unroll
     for (int l = 0; l < 5; ++l)
@@ -219,7 +231,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
                                      s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
                 s.PR[PH] = Rn + xt.RR;
                 o.Rn = at_end ? Rn : o.Rn;
-                pB[off] = Bj;
+                st_off(pB, off, Bj);
             }
         }
     }
@@ -254,7 +266,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     node(3, in.e0[0].w, in.e0[1].w, in.e0[2].w, in.e0[3].w, in.e0[4].w);
 
     // `in` is consumed: refill it for row j+1 while the other groups compute
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, wn);
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, wn);
 
 #pragma unroll
     for (int g = 1; g < G; ++g)
@@ -269,9 +281,9 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     if constexpr (!LAST)
     {
         // edges into the next tile's first node
-        pXm[off] = mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]);
-        pXd[off] = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
-        pEm[off] = E;
+        st_off(pXm, off, mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]));
+        st_off(pXd, off, fmaxf(pm + tr.md[KT], pd + tr.dd[KT]));
+        st_off(pEm, off, E);
     }
     else
     {
@@ -284,7 +296,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         if (live && B1 > Bj)
         {
             dirty = true;
-            pB[off] = B1;
+            st_off(pB, off, B1);
         }
         s.PJ[PH] = fmaxf(E + xt.EJ, J + xt.JJ);
         s.PC[PH] = fmaxf(E + xt.EC, C + xt.CC);
@@ -296,8 +308,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
 template <int G, bool FIRST, bool LAST, bool FI, int NT, int D>
-__device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float const *tabI,
-                                         float const *tabN, uint32_t const *__restrict__ words,
+__device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
+                                         uint32_t const *__restrict__ words,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
                                          SweepOut &o, unsigned wmask, unsigned rowstep)
@@ -325,7 +337,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
         s.PR[0] = 0.0f;
     }
     float *pB = sc, *pXm = sc + plane, *pXd = sc + 2 * plane, *pEm = sc + 3 * plane;
-    unsigned off = tid; // (j - 1) * 256 + tid
+    unsigned off = tid * 4u; // byte offset of ((j - 1) * NT + tid)
 
     // sequence window: w = row j, wn = row j+1 (the word past the last base is padding)
     // Every lane of the wavefront executes every row up to Lwave -- no per-lane
@@ -347,14 +359,14 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
         in.e0[l] = float4{ni, ni, ni, ni}, in.eI[l] = ni, in.eN[l] = ni;
         ring.B[l] = ring.Xm[l] = ring.Xd[l] = ring.Em[l] = ni;
     }
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabI, tabN, w);
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, w);
 #pragma unroll
     for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
-        ring_fetch<FIRST, FI>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT));
+        ring_fetch<FIRST, FI>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT * 4));
 
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
-        ql_row<G, FIRST, LAST, FI, PH, NT, D>(s, tr, tabM, tabI, tabN, w, wn, in, ring, pB, pXm,  \
+        ql_row<G, FIRST, LAST, FI, PH, NT, D>(s, tr, tabM, tabIN, w, wn, in, ring, pB, pXm,       \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o);                                              \
         /* advance the window: base of row j+2 sits at position j+1; sequence words */     \
@@ -367,7 +379,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float co
         }                                                                                  \
         w = wn;                                                                            \
         wn = ((wn << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & wmask;                     \
-        off += rowstep;                                                                     \
+        off += rowstep * 4u;                                                                     \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
         /* cross-row traffic is the explicit prefetch above (register budget)       */     \
@@ -404,7 +416,8 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
     constexpr int TAB_FLOATS = G * NC * 4;
     __shared__ __attribute__((aligned(16))) float lds[TAB_FLOATS + 2 * NC];
     __shared__ unsigned s_task;
-    float *tabM = lds, *tabI = lds + TAB_FLOATS, *tabN = tabI + NC;
+    float *tabM = lds;
+    float2 *tabIN = reinterpret_cast<float2 *>(lds + TAB_FLOATS); // [code] = {insert, background}
     unsigned const tid = threadIdx.x;
     // +8 rows: the software pipeline reads row j+D's boundary while computing row j
     size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
             for (unsigned i = tid; i < (unsigned)NC; i += (unsigned)NT)
-                tabI[i] = gi[i], tabN[i] = gn[i];
+                tabIN[i] = float2{gi[i], gn[i]};
         }
 
         SweepOut o{ninf(), ninf(), ninf()};
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
                 cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
                 bool const first = t == 0, last = t + 1 == T;
 #define QL_SWEEP(F, L_, FI_)                                                                     \
-    ql_sweep<G, F, L_, FI_, NT, D>(tt, tabM, tabI, tabN, words, L, Lwave, active, sc, plane, tid, \
+    ql_sweep<G, F, L_, FI_, NT, D>(tt, tabM, tabIN, words, L, Lwave, active, sc, plane, tid,      \
                                    xt, dirty, o, a.dbg_wmask, a.dbg_rowstep)
                 if (first_iter)
                 {
