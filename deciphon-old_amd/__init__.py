@@ -58,6 +58,8 @@ ABI_SYMBOLS = [
     "dcp_gpu_trace_paths", "dcp_state_name", "dcp_profile_decode", "dcp_gc_decode",
     "dcp_prod_format_row", "dcp_prod_header", "dcp_h3reader_open", "dcp_h3reader_next",
     "dcp_h3reader_error", "dcp_h3reader_close", "dcp_swissprot_null_lprobs", "dcp_profile_consensus",
+    "dcp_db_write", "dcp_db_open", "dcp_db_close", "dcp_db_nprofiles", "dcp_db_entry_dist", "dcp_db_epsilon",
+    "dcp_db_profile_sizes", "dcp_db_partitions", "dcp_db_read",
 ]
 
 
@@ -152,6 +154,15 @@ def _load():
         "dcp_h3reader_close": (None, [P]),
         "dcp_swissprot_null_lprobs": (None, [P]),
         "dcp_profile_consensus": (C.c_char_p, [P]),
+        "dcp_db_write": (I, [C.c_char_p, P, U]),
+        "dcp_db_open": (P, [C.c_char_p, C.POINTER(I)]),
+        "dcp_db_close": (None, [P]),
+        "dcp_db_nprofiles": (U, [P]),
+        "dcp_db_entry_dist": (I, [P]),
+        "dcp_db_epsilon": (F, [P]),
+        "dcp_db_profile_sizes": (C.POINTER(C.c_uint32), [P]),
+        "dcp_db_partitions": (U, [P, U, P, P]),
+        "dcp_db_read": (I, [P, U, U, P]),
         "dcp_gpu_scan_cells": (C.c_uint64, [P]),
         "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
     }
@@ -322,6 +333,62 @@ def read_hmmer3(path, cfg=PROTEIN_CFG_DEFAULT):
             out.append(ProteinProfile(h.value))
     finally:
         lib.dcp_h3reader_close(r)
+
+
+def write_db(path, profiles):
+    """Write a dcpx profile DB (the press output: protein_db_writer_pack_profile per profile)."""
+    arr = (C.c_void_p * len(profiles))(*[p._h for p in profiles])
+    rc = lib.dcp_db_write(str(path).encode(), arr, len(profiles))
+    if rc:
+        raise DcpError(rc, f"failed to write {path}")
+
+
+class ProfileDB:
+    """protein_db_reader + profile_reader over a dcpx file: header fields, per-profile byte sizes,
+    the reference's partition table, and reading a range of profiles."""
+
+    def __init__(self, path):
+        rc = C.c_int(0)
+        self._h = lib.dcp_db_open(str(path).encode(), C.byref(rc))
+        if not self._h:
+            raise DcpError(rc.value, f"failed to open {path}")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.dcp_db_close(h)
+
+    __del__ = close
+
+    @property
+    def nprofiles(self):
+        return lib.dcp_db_nprofiles(self._h)
+
+    @property
+    def cfg(self):
+        return ProteinCfg(lib.dcp_db_entry_dist(self._h), lib.dcp_db_epsilon(self._h))
+
+    @property
+    def profile_sizes(self):
+        return np.ctypeslib.as_array(lib.dcp_db_profile_sizes(self._h), shape=(self.nprofiles,)).copy()
+
+    def partitions(self, npartitions):
+        """(partition_size[npart], partition_offset[npart + 1]) as profile_reader_setup computes them."""
+        sizes = np.zeros(NUM_THREADS, np.uint32)
+        offs = np.zeros(NUM_THREADS + 1, np.int64)
+        n = lib.dcp_db_partitions(self._h, npartitions, sizes.ctypes.data, offs.ctypes.data)
+        if n == 0:
+            raise DcpError(RC_EINVAL, "can't have zero partitions / too many partitions")
+        return sizes[:n].tolist(), offs[:n + 1].tolist()
+
+    def read(self, begin=0, end=None):
+        end = self.nprofiles if end is None else end
+        out = (C.c_void_p * max(end - begin, 1))()
+        rc = lib.dcp_db_read(self._h, begin, end, out)
+        profs = [ProteinProfile(h) for h in out[:end - begin] if h]
+        if rc:
+            raise DcpError(rc, "failed to read profiles")
+        return profs
 
 
 def frame_table_host(dist, epsilon):

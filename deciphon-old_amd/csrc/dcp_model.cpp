@@ -833,3 +833,185 @@ int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// dcpx container
+// ---------------------------------------------------------------------------
+struct dcp_db
+{
+    FILE *fp = nullptr;
+    int entry_dist = 0;
+    float epsilon = 0;
+    std::vector<uint32_t> sizes;
+    int64_t profiles_offset = 0; // where the first profile starts
+    std::vector<int64_t> offsets; // per profile
+};
+
+namespace
+{
+constexpr uint16_t kDbMagic = 0xC6F0; // MAGIC_NUMBER, include/deciphon/db/types.h:11
+constexpr uint32_t kProfileProtein = 2; // PROFILE_PROTEIN, profile_typeid.h
+
+uint32_t profile_bytes(unsigned M)
+{
+    unsigned cons = (M + 3u) & ~3u;
+    return (uint32_t)(DCP_PROFILE_ACC_SIZE + 4 + cons + 4 * (8 * M + 2 * DCP_NDIST + (size_t)M * DCP_NDIST));
+}
+
+template <class T> bool wr(FILE *fp, T const *p, size_t n) { return std::fwrite(p, sizeof(T), n, fp) == n; }
+template <class T> bool rd(FILE *fp, T *p, size_t n) { return std::fread(p, sizeof(T), n, fp) == n; }
+} // namespace
+
+extern "C" {
+
+int dcp_db_write(char const *path, dcp_profile *const *profiles, unsigned n)
+{
+    if (!path || !profiles || n == 0 || n > (1u << 20)) return DCP_EINVAL;
+    for (unsigned i = 0; i < n; ++i)
+        if (!profiles[i] || profiles[i]->entry_dist != profiles[0]->entry_dist ||
+            profiles[i]->epsilon != profiles[0]->epsilon)
+            return DCP_EINVAL; // one protein_cfg per DB
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return DCP_EIO;
+    bool ok = true;
+    char const magic[4] = {'D', 'C', 'P', 'X'};
+    uint16_t const num = kDbMagic, version = 1;
+    uint32_t const typeid_ = kProfileProtein, float_size = 4, entry = (uint32_t)profiles[0]->entry_dist, count = n;
+    float const eps = profiles[0]->epsilon;
+    char abc[8] = "ACGT", amino[24] = "ACDEFGHIKLMNPQRSTVWY";
+    ok = ok && wr(fp, magic, 4) && wr(fp, &num, 1) && wr(fp, &version, 1) && wr(fp, &typeid_, 1) &&
+         wr(fp, &float_size, 1) && wr(fp, &entry, 1) && wr(fp, &eps, 1) && wr(fp, abc, 8) && wr(fp, amino, 24) &&
+         wr(fp, &count, 1);
+    std::vector<uint32_t> sizes(n);
+    for (unsigned i = 0; i < n; ++i)
+        sizes[i] = profile_bytes(profiles[i]->core_size);
+    ok = ok && wr(fp, sizes.data(), n);
+    for (unsigned i = 0; ok && i < n; ++i)
+    {
+        dcp_profile const *p = profiles[i];
+        uint32_t const M = p->core_size;
+        std::vector<char> cons((M + 3u) & ~3u, '\0');
+        std::memcpy(cons.data(), p->consensus.data(), M);
+        ok = wr(fp, p->accession, DCP_PROFILE_ACC_SIZE) && wr(fp, &M, 1) && wr(fp, cons.data(), cons.size()) &&
+             wr(fp, p->trans8.data(), (size_t)8 * M) && wr(fp, p->null_dist, DCP_NDIST) &&
+             wr(fp, p->insert_dist, DCP_NDIST) && wr(fp, p->match_dist.data(), (size_t)M * DCP_NDIST);
+    }
+    ok = std::fclose(fp) == 0 && ok;
+    return ok ? DCP_OK : DCP_EIO;
+}
+
+dcp_db *dcp_db_open(char const *path, int *rc)
+{
+    auto fail = [&](dcp_db *db, int code) -> dcp_db * {
+        if (rc) *rc = code;
+        if (db)
+        {
+            if (db->fp) std::fclose(db->fp);
+            delete db;
+        }
+        return nullptr;
+    };
+    if (!path) return fail(nullptr, DCP_EINVAL);
+    dcp_db *db = new (std::nothrow) dcp_db();
+    if (!db) return fail(nullptr, DCP_ENOMEM);
+    db->fp = std::fopen(path, "rb");
+    if (!db->fp) return fail(db, DCP_EIO);
+    char magic[4], abc[8], amino[24];
+    uint16_t num = 0, version = 0;
+    uint32_t typeid_ = 0, float_size = 0, entry = 0, count = 0;
+    float eps = 0;
+    if (!(rd(db->fp, magic, 4) && rd(db->fp, &num, 1) && rd(db->fp, &version, 1) && rd(db->fp, &typeid_, 1) &&
+          rd(db->fp, &float_size, 1) && rd(db->fp, &entry, 1) && rd(db->fp, &eps, 1) && rd(db->fp, abc, 8) &&
+          rd(db->fp, amino, 24) && rd(db->fp, &count, 1)))
+        return fail(db, DCP_EIO);
+    if (std::memcmp(magic, "DCPX", 4) != 0 || num != kDbMagic || version != 1) return fail(db, DCP_EINVAL); // invalid magic number
+    if (typeid_ != kProfileProtein) return fail(db, DCP_EINVAL);                                          // invalid typeid
+    if (float_size != 4) return fail(db, DCP_EINVAL);                                                     // invalid float size
+    if (entry <= DCP_ENTRY_DIST_NULL || entry > DCP_ENTRY_DIST_OCCUPANCY) return fail(db, DCP_EINVAL);   // invalid entry dist
+    if (!(eps >= 0.0f && eps <= 1.0f)) return fail(db, DCP_EINVAL);                                       // invalid epsilon
+    if (std::memcmp(abc, "ACGT", 5) != 0 || std::memcmp(amino, "ACDEFGHIKLMNPQRSTVWY", 21) != 0) return fail(db, DCP_EINVAL);
+    if (count == 0 || count > (1u << 20)) return fail(db, DCP_EINVAL); // MAX_NPROFILES
+    db->entry_dist = (int)entry;
+    db->epsilon = eps;
+    db->sizes.resize(count);
+    if (!rd(db->fp, db->sizes.data(), count)) return fail(db, DCP_EIO);
+    db->profiles_offset = (int64_t)std::ftell(db->fp);
+    db->offsets.resize((size_t)count + 1);
+    db->offsets[0] = db->profiles_offset;
+    for (uint32_t i = 0; i < count; ++i)
+        db->offsets[i + 1] = db->offsets[i] + db->sizes[i];
+    if (std::fseek(db->fp, 0, SEEK_END) != 0 || (int64_t)std::ftell(db->fp) != db->offsets[count])
+        return fail(db, DCP_EIO); // truncated or trailing bytes
+    if (rc) *rc = DCP_OK;
+    return db;
+}
+
+void dcp_db_close(dcp_db *db)
+{
+    if (!db) return;
+    if (db->fp) std::fclose(db->fp);
+    delete db;
+}
+
+unsigned dcp_db_nprofiles(dcp_db const *db) { return (unsigned)db->sizes.size(); }
+int dcp_db_entry_dist(dcp_db const *db) { return db->entry_dist; }
+float dcp_db_epsilon(dcp_db const *db) { return db->epsilon; }
+uint32_t const *dcp_db_profile_sizes(dcp_db const *db) { return db->sizes.data(); }
+
+unsigned dcp_db_partitions(dcp_db const *db, unsigned npartitions, unsigned part_size[DCP_NUM_THREADS],
+                           int64_t part_offset[DCP_NUM_THREADS + 1])
+{
+    // partition_init + partition_it, src/db/profile_reader.c:45-72
+    unsigned const nprofs = dcp_db_nprofiles(db);
+    unsigned const nparts = dcp_partition_by_count(nprofs, npartitions, part_size);
+    if (nparts == 0) return 0;
+    for (unsigned i = 0; i <= DCP_NUM_THREADS; ++i)
+        part_offset[i] = 0;
+    part_offset[0] = db->profiles_offset;
+    unsigned i = 0, size = 0;
+    for (unsigned j = 0; j < nprofs; ++j)
+    {
+        part_offset[i + 1] += db->sizes[j];
+        if (++size >= part_size[i])
+        {
+            part_offset[i + 1] += part_offset[i];
+            ++i;
+            size = 0;
+        }
+    }
+    return nparts;
+}
+
+int dcp_db_read(dcp_db *db, unsigned begin, unsigned end, dcp_profile **out)
+{
+    if (!db || !out || begin > end || end > dcp_db_nprofiles(db)) return DCP_EINVAL;
+    if (std::fseek(db->fp, (long)db->offsets[begin], SEEK_SET) != 0) return DCP_EIO;
+    for (unsigned i = begin; i < end; ++i)
+        out[i - begin] = nullptr;
+    for (unsigned i = begin; i < end; ++i)
+    {
+        dcp_profile *p = new (std::nothrow) dcp_profile();
+        if (!p) return DCP_ENOMEM;
+        out[i - begin] = p;
+        uint32_t M = 0;
+        if (!(rd(db->fp, p->accession, DCP_PROFILE_ACC_SIZE) && rd(db->fp, &M, 1))) return DCP_EIO;
+        p->accession[DCP_PROFILE_ACC_SIZE - 1] = '\0';
+        if (M == 0 || M > DCP_CORE_SIZE_MAX || profile_bytes(M) != db->sizes[i]) return DCP_EPARSE; // profile is too long
+        std::vector<char> cons((M + 3u) & ~3u);
+        p->core_size = M;
+        p->entry_dist = db->entry_dist;
+        p->epsilon = db->epsilon;
+        p->trans8.resize((size_t)8 * M);
+        p->match_dist.resize((size_t)M * DCP_NDIST);
+        if (!(rd(db->fp, cons.data(), cons.size()) && rd(db->fp, p->trans8.data(), (size_t)8 * M) &&
+              rd(db->fp, p->null_dist, DCP_NDIST) && rd(db->fp, p->insert_dist, DCP_NDIST) &&
+              rd(db->fp, p->match_dist.data(), (size_t)M * DCP_NDIST)))
+            return DCP_EIO;
+        p->consensus.assign(cons.begin(), cons.begin() + M);
+        p->consensus.push_back('\0');
+    }
+    return DCP_OK;
+}
+
+} // extern "C"
+

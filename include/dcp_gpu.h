@@ -122,6 +122,35 @@ void dcp_h3reader_close(dcp_h3reader *);
 void dcp_swissprot_null_lprobs(float out[DCP_AMINO_SIZE]);
 char const *dcp_profile_consensus(dcp_profile const *);
 
+/* ---- dcpx: compact on-disk profile DB (press once, scan many) ------------------------------
+ * Own little-endian container for what the scan needs (transitions + nuclt_dists; no per-state
+ * emission tables: the device expands them at upload). It is NOT the reference's .dcp: that is
+ * MessagePack with opaque imm_dp blobs whose format lives in the absent imm library. The header
+ * carries the reference's fields and its checks (src/db/protein_reader.c:40-82, src/db/reader.c:25-79):
+ * magic 0xC6F0 (include/deciphon/db/types.h:11), profile_typeid == PROFILE_PROTEIN, float_size == 4,
+ * entry_dist in {UNIFORM, OCCUPANCY}, 0 <= epsilon <= 1, alphabets, profile_sizes[] (u32 bytes per
+ * profile). One (entry_dist, epsilon) per DB, as protein_db_writer_open fixes it
+ * (src/db/protein_writer.c:56-96). */
+typedef struct dcp_db dcp_db;
+int dcp_db_write(char const *path, dcp_profile *const *profiles, unsigned nprofiles);
+/* NULL + *rc: DCP_EIO (cannot open / truncated), DCP_EINVAL (bad magic, typeid, float size,
+ * entry_dist, epsilon, too many profiles) */
+dcp_db *dcp_db_open(char const *path, int *rc);
+void dcp_db_close(dcp_db *);
+unsigned dcp_db_nprofiles(dcp_db const *);
+int dcp_db_entry_dist(dcp_db const *);
+float dcp_db_epsilon(dcp_db const *);
+uint32_t const *dcp_db_profile_sizes(dcp_db const *);
+/* profile_reader_setup's partition table for this file (src/db/profile_reader.c:45-72): count-balanced
+ * contiguous partitions, part_offset[i] = byte offset in the file where partition i starts,
+ * the end of the last non-empty partition = end of the profiles. ceil-sized partitions can leave
+ * trailing empty ones whose end offset the reference never writes (0): reproduced as is.
+ * Returns npart = min(npartitions, nprofiles); 0 on EINVAL. */
+unsigned dcp_db_partitions(dcp_db const *, unsigned npartitions, unsigned part_size[DCP_NUM_THREADS],
+                           int64_t part_offset[DCP_NUM_THREADS + 1]);
+/* Profiles [begin, end) (caller owns them). */
+int dcp_db_read(dcp_db *, unsigned begin, unsigned end, dcp_profile **out);
+
 /* Read-only views (host memory owned by the profile):
  *   trans8 [8][core_size]: rows entry(B->Mk), MM, IM, DM, MD, DD (edges INTO
  *   node k from node k-1) and MI, II (node k's own insert edges);
