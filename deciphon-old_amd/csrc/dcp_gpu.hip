@@ -81,6 +81,12 @@ struct dcp_gpu_ctx
     DevBuf<uint32_t> d_slot_of_pidx;
     std::vector<uint32_t> slot_of_pidx;
     DevBuf<float> d_emis_match, d_emis_insert, d_emis_null, d_trans8;
+    // the row-sweep layout of the match tables (d_emis_match) is expanded on first use: the
+    // throughput path only needs the tile images, and both together double the DB's footprint
+    DevBuf<float> d_dists, d_eps;
+    std::vector<dcp_expand_tile> rs_tiles;
+    uint64_t rs_floats = 0;
+    bool rs_ready = false;
     // query-lane kernel layout (dcp_qlane.hip)
     int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
     std::vector<dcp_ql_prof> ql_metas; // same order as metas
@@ -270,7 +276,13 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         c->slot_of_pidx[c->metas[i].pidx] = i;
     HIP_TRY(c, c->d_slot_of_pidx.alloc(nprofiles));
     HIP_TRY(c, hipMemcpy(c->d_slot_of_pidx.p, c->slot_of_pidx.data(), nprofiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
+    c->rs_floats = emis_floats;
+    c->rs_ready = false;
+    c->rs_tiles.clear();
+    c->d_emis_match.release();
+    c->d_dists.release();
+    c->d_eps.release();
+    if (expand_on_host) HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
     HIP_TRY(c, c->d_trans8.alloc(trans_floats));
     HIP_TRY(c, c->d_emis_insert.alloc((size_t)nprofiles * DCP_NCODES));
     HIP_TRY(c, c->d_emis_null.alloc((size_t)nprofiles * DCP_NCODES));
@@ -444,7 +456,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             }
         size_t const n_special_tiles = (tiles.size() - n_match_tiles - n_image_tiles) / 2;
 
-        DevBuf<float> d_dists, d_eps;
+        DevBuf<float> &d_dists = c->d_dists, &d_eps = c->d_eps; // kept for the lazy row-sweep layout
         DevBuf<dcp_expand_tile> d_tiles;
         HIP_TRY(c, d_dists.alloc(dists.size()));
         HIP_TRY(c, d_eps.alloc(eps.size()));
@@ -452,8 +464,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipMemcpy(d_dists.p, dists.data(), dists.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_eps.p, eps.data(), eps.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * sizeof(dcp_expand_tile), hipMemcpyHostToDevice));
-        dcp_expand_args ea{d_tiles.p, d_dists.p, d_eps.p, c->d_emis_match.p};
-        dcp_launch_expand(&ea, (unsigned)n_match_tiles, c->stream);
+        c->rs_tiles.assign(tiles.begin(), tiles.begin() + (long)n_match_tiles);
+        dcp_expand_args ea{d_tiles.p, d_dists.p, d_eps.p, nullptr};
         ea.tiles = d_tiles.p + n_match_tiles;
         ea.out = c->d_emis_tiles.p;
         dcp_launch_expand(&ea, (unsigned)n_image_tiles, c->stream);
@@ -466,7 +478,25 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    c->rs_ready = expand_on_host != 0;
     c->nprof = nprofiles;
+    return DCP_OK;
+}
+
+// Expand the row-sweep layout of the match tables ([1364][ldk] per profile) if it is not resident yet.
+static int ensure_rowsweep_layout(dcp_gpu_ctx *c)
+{
+    if (c->rs_ready) return DCP_OK;
+    if (c->rs_tiles.empty() || !c->d_dists.p) return c->fail(DCP_EFAIL, "row-sweep layout cannot be rebuilt");
+    HIP_TRY(c, c->d_emis_match.alloc(c->rs_floats));
+    DevBuf<dcp_expand_tile> d_tiles;
+    HIP_TRY(c, d_tiles.alloc(c->rs_tiles.size()));
+    HIP_TRY(c, hipMemcpy(d_tiles.p, c->rs_tiles.data(), c->rs_tiles.size() * sizeof(dcp_expand_tile), hipMemcpyHostToDevice));
+    dcp_expand_args ea{d_tiles.p, c->d_dists.p, c->d_eps.p, c->d_emis_match.p};
+    dcp_launch_expand(&ea, (unsigned)c->rs_tiles.size(), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->rs_ready = true;
     return DCP_OK;
 }
 
@@ -474,6 +504,7 @@ int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *c, unsigned p, float *out)
 {
     if (!c || !out || p >= c->nprof) return DCP_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = ensure_rowsweep_layout(c)) return rc;
     for (dcp_prof_meta const &m : c->metas)
         if (m.pidx == p)
         {
@@ -763,6 +794,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         c->scanned = true;
         return DCP_OK;
     }
+    if (int rc = ensure_rowsweep_layout(c)) return rc;
+    a.emis_match = c->d_emis_match.p;
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     for (int k = 0; k < kNumClasses; ++k)
     {
@@ -895,6 +928,7 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
         if (hits[h].seq_idx >= c->nseqs || hits[h].profile_idx >= c->nprof)
             return c->fail(DCP_EINVAL, "hit %u is outside the resident batch / DB", h);
     if (int rc = ensure_xtrans(c, multi_hits, hmmer3_compat)) return rc;
+    if (int rc = ensure_rowsweep_layout(c)) return rc;
 
     // per-hit work area and step capacity
     std::vector<uint64_t> need(nhits);
