@@ -93,7 +93,15 @@ struct dcp_gpu_ctx
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
+    DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block transposed sequence words
     DevBuf<unsigned> d_task_counter;
+    // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
+    // d_redo_n = [DCP_MAX_CLASSES counters][overflow flag]
+    DevBuf<dcp_pair> d_redo;
+    DevBuf<unsigned> d_redo_n;
+    bool redo_pending = false;      // the last scan's redo counters have not been checked yet
+    unsigned last_redo_pairs = 0;
+    struct dcp_scan_params last_prm = {};
     unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
     unsigned num_cus = 0;
     int last_kernel = 0; // 1 row sweep, 2 query lane
@@ -121,8 +129,8 @@ struct dcp_gpu_ctx
     unsigned *ext_nhits = nullptr;
     unsigned ext_cap = 0;
     // one HIP event after each size-class launch of the last scan
-    hipEvent_t ev_class[kNumClasses] = {nullptr};
-    int launched_class[kNumClasses] = {0};
+    hipEvent_t ev_class[kNumClasses + 1] = {nullptr};
+    int launched_class[kNumClasses + 1] = {0};
     unsigned n_launched = 0;
 
     int fail(int rc, char const *fmt, ...)
@@ -185,7 +193,7 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         c->ql_G = (int)dcp_qlane_tile_nodes() / 4;
     }
     bool ok = true;
-    for (int k = 0; k < kNumClasses; ++k)
+    for (int k = 0; k <= kNumClasses; ++k)
         ok = ok && hipEventCreate(&c->ev_class[k]) == hipSuccess;
     if (!ok)
     {
@@ -203,7 +211,7 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    for (int k = 0; k < kNumClasses; ++k)
+    for (int k = 0; k <= kNumClasses; ++k)
         if (c->ev_class[k]) (void)hipEventDestroy(c->ev_class[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -316,6 +324,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         dcp_ql_prof &qm = c->ql_metas[i];
         qm.core_size = m.core_size;
         qm.pidx = m.pidx;
+        qm.rs_slot = i; // ql_metas and metas share one order
+        qm.cls = (uint32_t)class_of(m.core_size);
         qm.ntiles = (m.core_size + KT - 1) / KT;
         qm.tile_off = tile_floats;
         qm.ttrans_off = (uint32_t)ttrans_floats;
@@ -728,7 +738,28 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 lmax = std::max(lmax, c->seq_len[q]);
             if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
             HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // per block of NT queries: (longest member / 16 + 3) word rows, transposed
+            unsigned const NTq = dcp_qlane_block_size();
+            unsigned const nqb = (nq + NTq - 1u) / NTq;
+            std::vector<uint32_t> wt_off(nqb + 1u, 0u);
+            uint64_t tot = 0;
+            for (unsigned b = 0; b < nqb; ++b)
+            {
+                unsigned const lastq = std::min(nq, (b + 1u) * NTq) - 1u; // ascending lengths
+                tot += (uint64_t)(c->seq_len[q_begin + ord[lastq]] / 16u + 3u) * NTq;
+                if (tot > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
+                wt_off[b + 1u] = (uint32_t)tot;
+            }
+            if (c->d_wt_off.n < nqb + 1u) HIP_TRY(c, c->d_wt_off.alloc(nqb + 1u));
+            if (c->d_words_t.n < tot) HIP_TRY(c, c->d_words_t.alloc((size_t)tot));
+            HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off.data(), (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            dcp_qlane_args ta{};
+            ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
+            ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
+            ta.nseqs = nq, ta.nqblocks = nqb;
+            dcp_launch_qlane_transpose(&ta, c->stream);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // ord / wt_off are stack-local
             c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax;
         }
         if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
@@ -750,6 +781,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.seq_len = a.seq_len;
         qa.xtrans = a.xtrans;
         qa.qorder = c->d_qorder.p;
+        qa.words_t = c->d_words_t.p;
+        qa.wt_off = c->d_wt_off.p;
         qa.task_counter = c->d_task_counter.p;
         qa.out_null = a.out_null;
         qa.out_alt = a.out_alt;
@@ -774,9 +807,43 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
-        // scratch = 4 planes x (lmax + 8) rows x NT floats per resident block; long sequences
+        // redo lists: pairs whose multi-hit feedback beat B0 go to the row-sweep kernel, which
+        // runs right behind the query-lane kernel on this stream (uni-hit scans have no feedback)
+        bool const redo = prm->multi_hits != 0;
+        unsigned redo_grid[kNumClasses] = {0};
+        if (redo)
+        {
+            if (int rc = ensure_rowsweep_layout(c)) return rc;
+            a.emis_match = c->d_emis_match.p;
+            uint64_t tot = 0;
+            uint64_t cap_limit = 1u << 24; // per size class; DCP_REDO_CAP: tests of the overflow path
+            if (char const *e = getenv("DCP_REDO_CAP")) cap_limit = (uint64_t)std::max(1, atoi(e));
+            for (int k = 0; k < kNumClasses; ++k)
+            {
+                uint64_t const pairs = (uint64_t)nq * (c->class_first[k + 1] - c->class_first[k]);
+                unsigned const cap = (unsigned)std::min<uint64_t>(pairs, cap_limit);
+                qa.redo_base[k] = (unsigned)tot;
+                qa.redo_cap[k] = cap;
+                tot += cap;
+                uint64_t const tpb = dcp_rowsweep_tasks_per_block(kClasses[k].W);
+                uint64_t g = std::min<uint64_t>((cap + tpb - 1) / tpb, 8ull * c->num_cus);
+                redo_grid[k] = (unsigned)((g + 7) / 8 * 8);
+            }
+            if (c->d_redo.n < tot) HIP_TRY(c, c->d_redo.alloc((size_t)tot));
+            if (!c->d_redo_n.p) HIP_TRY(c, c->d_redo_n.alloc(DCP_MAX_CLASSES + 1));
+            HIP_TRY(c, hipMemsetAsync(c->d_redo_n.p, 0, (DCP_MAX_CLASSES + 1) * sizeof(unsigned), c->stream));
+        }
+        else if (!c->d_redo_n.p)
+        {
+            HIP_TRY(c, c->d_redo_n.alloc(DCP_MAX_CLASSES + 1)); // caps are 0: never written
+            HIP_TRY(c, hipMemsetAsync(c->d_redo_n.p, 0, (DCP_MAX_CLASSES + 1) * sizeof(unsigned), c->stream));
+        }
+        qa.redo = c->d_redo.p;
+        qa.redo_n = c->d_redo_n.p;
+        qa.redo_overflow = c->d_redo_n.p + DCP_MAX_CLASSES;
+        // scratch = 3 planes x (lmax + 8) rows x NT floats per resident block; long sequences
         // (SCHED_SEQ_SIZE allows 1 MiB) get fewer resident blocks so the planes stay within budget
-        uint64_t const per_block = 4ull * ((uint64_t)qa.lmax + 8u) * NT; // floats
+        uint64_t const per_block = (uint64_t)dcp_qlane_scratch_planes() * ((uint64_t)qa.lmax + 8u) * NT; // floats
         uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
         uint64_t fit = per_block ? budget / per_block : 0;
         unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, 2ull * c->num_cus), fit);
@@ -788,14 +855,37 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
         if (dcp_launch_qlane(&qa, nblocks, c->stream)) return c->fail(DCP_EFAIL, "query-lane launch failed");
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
+        c->launched_class[c->n_launched++] = -1;
         c->last_launches = 1;
+        for (int k = 0; redo && k < kNumClasses; ++k)
+        {
+            if (redo_grid[k] == 0) continue;
+            a.pairs = c->d_redo.p + qa.redo_base[k];
+            a.npairs = c->d_redo_n.p + k;
+            a.pair_cap = qa.redo_cap[k];
+            a.first_prof = 0;
+            a.nprof = c->nprof;
+            SizeClass const sc = kClasses[k];
+            if (dcp_launch_rowsweep(sc.R, sc.W, &a, redo_grid[k], c->stream))
+                return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
+            HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
+            c->launched_class[c->n_launched++] = k;
+            c->last_launches++;
+        }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
         c->scanned = true;
+        c->redo_pending = redo;
+        c->last_redo_pairs = 0;
+        c->last_prm = *prm;
         return DCP_OK;
     }
     if (int rc = ensure_rowsweep_layout(c)) return rc;
     a.emis_match = c->d_emis_match.p;
+    c->redo_pending = false;
+    c->last_redo_pairs = 0;
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     for (int k = 0; k < kNumClasses; ++k)
     {
@@ -808,7 +898,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t ntasks = (uint64_t)a.nprof * a.nchunks;
         uint64_t nblocks = (ntasks + tpb - 1) / tpb;
         nblocks = (nblocks + 7) / 8 * 8;
-        if (nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
+        if (ntasks > 0xffffffffull || nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, c->stream))
             return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
@@ -821,11 +911,42 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     return DCP_OK;
 }
 
+// Wait for the stream; after a query-lane scan also look at the redo counters.  A redo list
+// that overflowed (> 2^24 pairs of one size class needed the row sweep) lost pairs: the scan is
+// repeated with the row-sweep kernel, which needs no list.
+static int finish_scan(dcp_gpu_ctx *c)
+{
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->redo_pending) return DCP_OK;
+    c->redo_pending = false;
+    unsigned n[DCP_MAX_CLASSES + 1];
+    HIP_TRY(c, hipMemcpy(n, c->d_redo_n.p, sizeof n, hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (int k = 0; k < kNumClasses; ++k)
+        tot += n[k];
+    c->last_redo_pairs = (unsigned)std::min<uint64_t>(tot, 0xffffffffull);
+    if (n[DCP_MAX_CLASSES] == 0) return DCP_OK;
+    struct dcp_scan_params prm = c->last_prm;
+    prm.kernel = 1;
+    if (int rc = dcp_gpu_scan_range(c, &prm, c->last_q0, c->last_q1)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCP_OK;
+}
+
 int dcp_gpu_sync(dcp_gpu_ctx *c)
 {
     if (!c) return DCP_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return finish_scan(c);
+}
+
+int dcp_gpu_last_scan_redo_pairs(dcp_gpu_ctx *c, unsigned *npairs)
+{
+    if (!c || !npairs) return DCP_EINVAL;
+    if (!c->scanned) return c->fail(DCP_EINVAL, "no scan yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = finish_scan(c)) return rc;
+    *npairs = c->last_redo_pairs;
     return DCP_OK;
 }
 
@@ -843,11 +964,14 @@ unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *c) { return c ? c->last_l
 int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_info *out)
 {
     if (!c || !out || !c->scanned) return DCP_EINVAL;
-    if (c->last_kernel == 2)
+    if (i >= c->n_launched) return DCP_EINVAL;
+    int const k = c->launched_class[i];
+    hipEvent_t const before = i == 0 ? c->ev_start : c->ev_class[i - 1];
+    if (hipEventSynchronize(c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, before, c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
+    if (k < 0) // the query-lane launch: every pair of the scan
     {
-        if (i != 0) return DCP_EINVAL;
-        float ms = dcp_gpu_last_scan_ms(c);
-        if (ms < 0) return DCP_EFAIL;
         out->nodes_per_lane = 4 * c->ql_G; // KT nodes per tile, one query per lane
         out->waves_per_pair = 0;
         out->nprofiles = c->nprof;
@@ -856,12 +980,16 @@ int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_
         out->algorithmic_bytes = dcp_gpu_scan_algorithmic_bytes(c);
         return DCP_OK;
     }
-    if (i >= c->n_launched) return DCP_EINVAL;
-    int const k = c->launched_class[i];
-    hipEvent_t const before = i == 0 ? c->ev_start : c->ev_class[i - 1];
-    if (hipEventSynchronize(c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, before, c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
+    if (c->last_kernel == 2) // a redo launch: its pairs are counted in the query-lane launch
+    {
+        out->nodes_per_lane = kClasses[k].R;
+        out->waves_per_pair = kClasses[k].W;
+        out->nprofiles = c->class_first[k + 1] - c->class_first[k];
+        out->ms = ms;
+        out->cells = 0;
+        out->algorithmic_bytes = 0;
+        return DCP_OK;
+    }
     uint64_t sumM = 0, np = 0, len = 0;
     for (unsigned j = c->class_first[k]; j < c->class_first[k + 1]; ++j, ++np)
         sumM += c->metas[j].core_size;
@@ -882,7 +1010,7 @@ int dcp_gpu_fetch_scores(dcp_gpu_ctx *c, float *null_out, float *alt_out)
     if (!c) return DCP_EINVAL;
     if (!c->scanned || !c->have_scores) return c->fail(DCP_EINVAL, "no dense scores kept by the last scan");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = finish_scan(c)) return rc;
     size_t const bytes = (size_t)c->nseqs * c->nprof * sizeof(float);
     if (null_out) HIP_TRY(c, hipMemcpy(null_out, c->d_null.p, bytes, hipMemcpyDeviceToHost));
     if (alt_out) HIP_TRY(c, hipMemcpy(alt_out, c->d_alt.p, bytes, hipMemcpyDeviceToHost));
@@ -894,7 +1022,7 @@ int dcp_gpu_fetch_hits(dcp_gpu_ctx *c, struct dcp_hit *hits, unsigned cap, unsig
     if (!c || !nhits) return DCP_EINVAL;
     if (!c->scanned) return c->fail(DCP_EINVAL, "no scan to fetch hits from");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = finish_scan(c)) return rc;
     unsigned n = 0;
     dcp_hit const *const hits_p = c->ext_hits ? c->ext_hits : c->d_hits.p;
     unsigned const hits_cap = c->ext_hits ? c->ext_cap : c->hit_cap;

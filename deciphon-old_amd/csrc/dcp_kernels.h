@@ -15,6 +15,14 @@ struct dcp_prof_meta
     uint32_t pidx;      // index in the caller's profile order
 };
 
+// a (query, profile) pair the query-lane kernel hands to the row-sweep kernel
+struct dcp_pair
+{
+    uint32_t q;    // sequence index relative to the scan's first
+    uint32_t slot; // entry of profs[] (row-sweep order)
+};
+#define DCP_MAX_CLASSES 16
+
 struct dcp_scan_args
 {
     dcp_prof_meta const *profs;
@@ -39,6 +47,11 @@ struct dcp_scan_args
     unsigned q_base; // index of the first one in the resident batch (hit records)
     unsigned qchunk;  // queries per task
     unsigned nchunks; // ceil(nseqs / qchunk)
+    // pair mode (pairs != NULL): task i = pairs[i], i < min(*npairs, pair_cap); the grid is
+    // persistent and strides over the list (its length is only known on the device)
+    dcp_pair const *pairs;
+    unsigned const *npairs;
+    unsigned pair_cap;
 };
 
 // One 64-column tile of the expansion kernel.
@@ -89,6 +102,8 @@ struct dcp_ql_prof
     uint32_t core_size;
     uint32_t ntiles;     // T = ceil(core_size / KT)
     uint32_t pidx;
+    uint32_t rs_slot;    // this profile's entry in the row-sweep kernel's profs[]
+    uint32_t cls;        // its row-sweep size class (redo list to append to)
 };
 
 struct dcp_qlane_args
@@ -103,8 +118,19 @@ struct dcp_qlane_args
     uint32_t const *seq_len;
     float const *xtrans;
     uint32_t const *qorder;   // [nseqs] query indices sorted by length
-    float *scratch;           // [nblocks][4 planes][lmax + 8][queries per block]
+    // sequence words of each block of queries, transposed: block qb's word w of lane t sits at
+    // words_t[wt_off[qb] + w * (queries per block) + t] -- one coalesced load per row
+    uint32_t *words_t;
+    uint32_t const *wt_off;   // [nqblocks + 1]
+    float *scratch;           // [nblocks][3 (or 4) planes][lmax + 8][queries per block]
     unsigned *task_counter;
+    // redo lists, one per row-sweep size class: pairs whose B0(j) = N(j) + NB was beaten by the
+    // E -> B / J -> B feedback (dcp_qlane.hip header)
+    dcp_pair *redo;
+    unsigned *redo_n;        // [DCP_MAX_CLASSES] appended so far (may exceed the capacity)
+    unsigned *redo_overflow; // set when a list overflowed
+    unsigned redo_base[DCP_MAX_CLASSES];
+    unsigned redo_cap[DCP_MAX_CLASSES];
     float *out_null;
     float *out_alt;
     dcp_hit *hits;
@@ -141,9 +167,11 @@ int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
 int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream);
+void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream);
 void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);
+unsigned dcp_qlane_scratch_planes(void);
 #ifdef __cplusplus
 }
 #endif

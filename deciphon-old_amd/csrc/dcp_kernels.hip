@@ -319,13 +319,28 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
     // same few profiles).  Placement only affects speed, never results.
     unsigned const nblk = gridDim.x; // multiple of 8
     unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    unsigned const task = W == 1 ? vblk * TASKS_PER_BLOCK + wave : vblk;
-    unsigned const nchunks = a.nchunks;
-    unsigned const slot = task / nchunks;
-    if (slot >= a.nprof) return; // uniform per task: whole block for W > 1
-    unsigned const chunk = task - slot * nchunks;
+    unsigned task = W == 1 ? vblk * TASKS_PER_BLOCK + wave : vblk;
+    // pair mode: the grid is persistent and strides over a device-side list of (query,
+    // profile) pairs -- the pairs the query-lane kernel could not finish (dcp_qlane.hip)
+    bool const pair_mode = a.pairs != nullptr;
+    unsigned const ntasks = pair_mode ? min(*a.npairs, a.pair_cap) : a.nprof * a.nchunks;
+    for (; task < ntasks; task += nblk * TASKS_PER_BLOCK) // uniform per task: whole block for W > 1
+    {
+    unsigned slot, q0, q1;
+    if (pair_mode)
+    {
+        dcp_pair const pr = a.pairs[task];
+        slot = pr.slot, q0 = pr.q, q1 = pr.q + 1u;
+    }
+    else
+    {
+        unsigned const s_rel = task / a.nchunks;
+        slot = a.first_prof + s_rel;
+        q0 = (task - s_rel * a.nchunks) * a.qchunk;
+        q1 = min(q0 + a.qchunk, a.nseqs);
+    }
 
-    dcp_prof_meta const pm = a.profs[a.first_prof + slot];
+    dcp_prof_meta const pm = a.profs[slot];
     float const *__restrict__ em_base = a.emis_match + pm.emis_off;
     float const *__restrict__ eN_tab = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
     float const *__restrict__ eI_tab = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
     unsigned gen = 0;
     if constexpr (W > 1)
     {
+        __syncthreads(); // pair mode: the previous task's last exchange is over
         if (threadIdx.x == 0) xc->flag[0] = xc->flag[1] = xc->flag[2] = 0;
         __syncthreads();
     }
@@ -351,8 +367,6 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
         VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
     }
 
-    unsigned const q0 = chunk * a.qchunk;
-    unsigned const q1 = min(q0 + a.qchunk, a.nseqs);
     for (unsigned q = q0; q < q1; ++q)
     {
         unsigned const L = a.seq_len[q];
@@ -426,6 +440,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
                     a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
             }
         }
+    }
+    if (!pair_mode) break; // grid mode: one task per wavefront (W == 1) or block
     }
 }
 

@@ -11,15 +11,20 @@
 // delete chain is sequential in k inside the lane.
 //
 // Multi-hit feedback (B(j) needs E(j) of the same row, which needs every tile):
-// iteration 0 runs with B0(j) = N(j) + NB only; the last tile then knows E(j),
-// J(j) and checks whether max(E(j)+EB, J(j)+JB) exceeds the B(j) that was used.
-// If it never does, B0 IS the solution of the recurrence (the system is a forward
-// recurrence in j, so its solution is unique) and the scores are exact; otherwise
-// the improved B is stored and the pair is swept again, until nothing changes.
-// Values only grow and are bounded by the true ones, so the loop ends at the
-// exact Viterbi scores -- bit-identical to the row sweep of dcp_kernels.hip and
-// to the oracle.  Reference recursion: imm_dp_viterbi as driven by
-// src/server/scan_thread.c:99-123; model wiring src/model/protein_model.c:410-500.
+// the sweep runs with B0(j) = N(j) + NB only; the last tile then knows E(j), J(j)
+// and checks whether max(E(j)+EB, J(j)+JB) exceeds the B(j) that was used.  If it
+// never does, B0 IS the solution of the recurrence (a forward recurrence in j, so
+// its solution is unique) and the lane's scores are exact -- bit-identical to the
+// row sweep of dcp_kernels.hip and to the oracle.  A lane where it does (a pair
+// with a local match good enough to re-enter the core: ~0.2 % of random pairs)
+// publishes nothing and appends its (query, profile) to the redo list of the
+// profile's size class; the row-sweep kernel, which has the whole row in one
+// wavefront group and therefore the exact B(j), scores those pairs right after
+// this kernel on the same stream.  (Re-sweeping in place until nothing changes
+// is also exact, but one such lane costs its whole wavefront another full pass:
+// 13 % of the scan time on the C3 workload.)
+// Reference recursion: imm_dp_viterbi as driven by src/server/scan_thread.c:99-123;
+// model wiring src/model/protein_model.c:410-500.
 #include "dcp_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -28,13 +33,14 @@ namespace
 {
 constexpr int NC = DCP_NCODES;
 
-// Iteration 0 needs B0(j) = N(j) + NB in every tile.  RECOMPUTE_B: every tile re-derives N(j)
-// from the background table (12 VALU + 5 LDS gathers per row) instead of reading the B plane
-// (4 of the 28 scratch bytes per row and tile).
+// Every tile needs B0(j) = N(j) + NB.  RECOMPUTE_B: every tile re-derives N(j) from the
+// background table (12 VALU per row; the gathers are shared with the insert table) instead
+// of reading a fourth scratch plane written by the first tile (4 more bytes per row and tile).
 #ifndef DCP_QLANE_RECOMPUTE_B
 #define DCP_QLANE_RECOMPUTE_B 1
 #endif
 constexpr bool kRecomputeB = DCP_QLANE_RECOMPUTE_B != 0;
+constexpr unsigned kPlanes = kRecomputeB ? 3u : 4u; // scratch planes per block: Xm, Xd, Em (, B0)
 
 // Read-only tables are accessed through the constant address space: the data
 // never changes during the kernel, and loads at wave-uniform addresses then
@@ -141,18 +147,28 @@ struct Ring
     float B[5], Xm[5], Xd[5], Em[5];
 };
 
-template <bool FIRST, bool FI>
-__device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, float const *pXm,
-                                           float const *pXd, float const *pEm, unsigned off)
+template <bool FIRST>
+__device__ __forceinline__ void ring_fetch_x(Ring &r, int slot, float const *pXm, float const *pXd,
+                                             float const *pEm, unsigned off)
 {
-    constexpr bool first_iter = FI;
     if constexpr (!FIRST)
     {
         r.Xm[slot] = ld_off(pXm, off);
         r.Xd[slot] = ld_off(pXd, off);
         r.Em[slot] = ld_off(pEm, off);
     }
-    if constexpr (kRecomputeB ? !first_iter : (!FIRST || !first_iter)) r.B[slot] = ld_off(pB, off);
+}
+template <bool FIRST>
+__device__ __forceinline__ void ring_fetch_b(Ring &r, int slot, float const *pB, unsigned off)
+{
+    if constexpr (!kRecomputeB && !FIRST) r.B[slot] = ld_off(pB, off);
+}
+template <bool FIRST>
+__device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, float const *pXm,
+                                           float const *pXd, float const *pEm, unsigned off)
+{
+    ring_fetch_x<FIRST>(r, slot, pXm, pXd, pEm, off);
+    ring_fetch_b<FIRST>(r, slot, pB, off);
 }
 
 template <int G, bool FIRST, bool LAST>
@@ -178,14 +194,13 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, bool FI, int PH, int NT, int D>
+template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float2 const *tabIN, unsigned w,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned off, LaneXt const &xt,
                                        bool live, bool at_end, bool &dirty, SweepOut &o)
 {
-    constexpr bool first_iter = FI; // compile time: no branch inside the row body
     constexpr int KT = 4 * G;
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;
     float const ni = ninf();
@@ -205,8 +220,6 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         Xd = ring.Xd[PH];
         E = ring.Em[PH];
     }
-    // fetch row j+D into its slot (slot PH itself when D == 5: it is consumed above)
-    ring_fetch<FIRST, FI>(ring, (PH + D) % 5, pB, pXm, pXd, pEm, off + (unsigned)(D * NT * 4));
     float eI[5], eN[5];
 #pragma unroll
     for (int l = 0; l < 5; ++l)
@@ -217,22 +230,19 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
     if constexpr (FIRST || kRecomputeB)
     {
-        if constexpr (first_iter)
+        // N(j); B0(j) = N(j) + NB  (S(j>0) = -inf).  The first tile also runs the null
+        // model R(j).
+        float const N = mx5(s.PN[s1] + eN[0], s.PN[s2] + eN[1], s.PN[s3] + eN[2],
+                            s.PN[s4] + eN[3], s.PN[s5] + eN[4]);
+        s.PN[PH] = N + xt.NN;
+        Bj = N + xt.NB;
+        if constexpr (FIRST)
         {
-            // N(j); B0(j) = N(j) + NB  (S(j>0) = -inf).  The first tile also runs the null
-            // model R(j) and publishes B0 for the (rare) later iterations.
-            float const N = mx5(s.PN[s1] + eN[0], s.PN[s2] + eN[1], s.PN[s3] + eN[2],
-                                s.PN[s4] + eN[3], s.PN[s5] + eN[4]);
-            s.PN[PH] = N + xt.NN;
-            Bj = N + xt.NB;
-            if constexpr (FIRST)
-            {
-                float const Rn = mx5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
-                                     s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
-                s.PR[PH] = Rn + xt.RR;
-                o.Rn = at_end ? Rn : o.Rn;
-                st_off(pB, off, Bj);
-            }
+            float const Rn = mx5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
+                                 s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
+            s.PR[PH] = Rn + xt.RR;
+            o.Rn = at_end ? Rn : o.Rn;
+            if constexpr (!kRecomputeB) st_off(pB, off, Bj);
         }
     }
 
@@ -265,6 +275,18 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     node(2, in.e0[0].z, in.e0[1].z, in.e0[2].z, in.e0[3].z, in.e0[4].z);
     node(3, in.e0[0].w, in.e0[1].w, in.e0[2].w, in.e0[3].w, in.e0[4].w);
 
+    // fetch row j+D's boundary into its ring slot (slot PH itself when D == 5).  The slot's
+    // old values died in node 0; the empty asm ties the load's address to group 0's E so the
+    // scheduler cannot hoist the load above that point -- while old and new overlap the
+    // allocator gives the new value another register and copies it into place at the loop's
+    // back edge, and that copy waits for a load issued half a row earlier.  (B is in use
+    // until the last node: its slot is refilled at the end of the row.)
+    {
+        unsigned roff = off + (unsigned)(D * NT * 4);
+        asm volatile("" : "+v"(roff) : "v"(E));
+        ring_fetch_x<FIRST>(ring, (PH + D) % 5, pXm, pXd, pEm, roff);
+    }
+
     // `in` is consumed: refill it for row j+1 while the other groups compute
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, wn);
 
@@ -276,6 +298,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         node(4 * g + 1, eg[0].y, eg[1].y, eg[2].y, eg[3].y, eg[4].y);
         node(4 * g + 2, eg[0].z, eg[1].z, eg[2].z, eg[3].z, eg[4].z);
         node(4 * g + 3, eg[0].w, eg[1].w, eg[2].w, eg[3].w, eg[4].w);
+    }
+
+    {
+        unsigned roff = off + (unsigned)(D * NT * 4);
+        asm volatile("" : "+v"(roff) : "v"(pm));
+        ring_fetch_b<FIRST>(ring, (PH + D) % 5, pB, roff);
     }
 
     if constexpr (!LAST)
@@ -291,13 +319,10 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
                             s.PJ[s5] + eN[4]);
         float const C = mx5(s.PC[s1] + eN[0], s.PC[s2] + eN[1], s.PC[s3] + eN[2], s.PC[s4] + eN[3],
                             s.PC[s5] + eN[4]);
-        // did E(j) -> B(j) or J(j) -> B(j) beat the B(j) this sweep ran with?
+        // did E(j) -> B(j) or J(j) -> B(j) beat the B(j) this sweep ran with?  Then this
+        // pair goes to the redo list (nothing computed from here on is used)
         float const B1 = fmaxf(E + xt.EB, J + xt.JB);
-        if (live && B1 > Bj)
-        {
-            dirty = true;
-            st_off(pB, off, B1);
-        }
+        dirty = dirty || (live && B1 > Bj);
         s.PJ[PH] = fmaxf(E + xt.EJ, J + xt.JJ);
         s.PC[PH] = fmaxf(E + xt.EC, C + xt.CC);
         o.E = at_end ? E : o.E;
@@ -307,9 +332,9 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST, bool FI, int NT, int D>
+template <int G, bool FIRST, bool LAST, int NT, int D>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
-                                         uint32_t const *__restrict__ words,
+                                         uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
                                          SweepOut &o, unsigned wmask, unsigned rowstep)
@@ -336,7 +361,8 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         s.PN[0] = 0.0f + xt.SN;
         s.PR[0] = 0.0f;
     }
-    float *pB = sc, *pXm = sc + plane, *pXd = sc + 2 * plane, *pEm = sc + 3 * plane;
+    // plane 3 (B0) exists only when the tiles do not recompute N themselves
+    float *pXm = sc, *pXd = sc + plane, *pEm = sc + 2 * plane, *pB = sc + (kRecomputeB ? 0 : 3) * plane;
     unsigned off = tid * 4u; // byte offset of ((j - 1) * NT + tid)
 
     // sequence window: w = row j, wn = row j+1 (the word past the last base is padding)
@@ -347,10 +373,16 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (or without a query) computes garbage into its own scratch column and its
     // own registers; its results were captured at row L (`at_end`), `live` guards
     // the only externally visible effects.
-    unsigned const wlast = L / 16u + 2u; // last word of this lane's sequence (incl. padding)
-    unsigned cur = words[0], nxt = words[1], j = 1;
-    unsigned w = cur & 3u & wmask;
-    unsigned wn = ((w << 2) | ((cur >> 2) & 3u)) & wmask;
+    // Sequence words come from the block's transposed plane (word index uniform, lane =
+    // column): every row issues ONE coalesced load, five rows ahead of its use like the
+    // boundary ring, so the in-order vmcnt wait for it never drains younger prefetches.
+    // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
+    // phi copy and costs a vmcnt(0) drain each time.)
+    unsigned j = 1;
+    unsigned const w0 = wordsT[tid];
+    unsigned wq[5] = {w0, w0, w0, w0, w0}; // rows 1..5 take bases 2..6: all in word 0
+    unsigned w = w0 & 3u & wmask;
+    unsigned wn = ((w << 2) | ((w0 >> 2) & 3u)) & wmask;
     RowIn in;
     Ring ring;
 #pragma unroll
@@ -362,23 +394,18 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, w);
 #pragma unroll
     for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
-        ring_fetch<FIRST, FI>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT * 4));
+        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT * 4));
 
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
-        ql_row<G, FIRST, LAST, FI, PH, NT, D>(s, tr, tabM, tabIN, w, wn, in, ring, pB, pXm,       \
+        /* base of row j+2 sits at position j+1 */                                         \
+        unsigned const pos = j + 1u;                                                       \
+        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabIN, w, wn, in, ring, pB, pXm,       \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o);                                              \
-        /* advance the window: base of row j+2 sits at position j+1; sequence words */     \
-        /* are fetched one word (16 rows) ahead, clamped to the lane's own sequence */     \
-        unsigned const pos = j + 1u;                                                       \
-        if ((pos & 15u) == 0u)                                                             \
-        {                                                                                  \
-            cur = nxt;                                                                     \
-            nxt = words[min((pos >> 4) + 1u, wlast)];                                      \
-        }                                                                                  \
         w = wn;                                                                            \
-        wn = ((wn << 2) | ((cur >> ((pos & 15u) * 2u)) & 3u)) & wmask;                     \
+        wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
+        wq[PH] = wordsT[((pos + 5u) >> 4) * (unsigned)NT + tid]; /* for row j + 5 */        \
         off += rowstep * 4u;                                                                     \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
     unsigned const tid = threadIdx.x;
     // +8 rows: the software pipeline reads row j+D's boundary while computing row j
     size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
-    float *const sc = a.scratch + (size_t)blockIdx.x * 4u * plane; // wave-uniform base
+    float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane; // wave-uniform base
 
     for (;;)
     {
@@ -440,7 +467,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
         bool const has = qi < a.nseqs;
         unsigned const q = has ? a.qorder[qi] : 0u;
         unsigned const L = has ? a.seq_len[q] : 0u;
-        uint32_t const *__restrict__ words = a.seq_words + a.seq_woff[q];
+        uint32_t const *__restrict__ wordsT = a.words_t + a.wt_off[qb]; // wave-uniform
         LaneXt xt;
         {
             float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
@@ -460,50 +487,40 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 
         SweepOut o{ninf(), ninf(), ninf()};
         bool dirty = false;
-        bool first_iter = true;
-        for (;;)
+        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
+        for (unsigned t = 0; t < T; ++t)
         {
-            bool const active = has && (first_iter || dirty);
-            unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(active ? L : 0u));
-            dirty = false;
-            for (unsigned t = 0; t < T; ++t)
+            __syncthreads(); // previous tile's readers are done with tabM
             {
-                __syncthreads(); // previous tile's readers are done with tabM
-                {
-                    float4 const *__restrict__ src = reinterpret_cast<float4 const *>(
-                        a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
-                    float4 *dst = reinterpret_cast<float4 *>(tabM);
-                    for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
-                        dst[i] = src[i];
-                }
-                __syncthreads();
-                if (Lwave == 0u) continue; // no lane of this wavefront has work
-                cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
-                bool const first = t == 0, last = t + 1 == T;
-#define QL_SWEEP(F, L_, FI_)                                                                     \
-    ql_sweep<G, F, L_, FI_, NT, D>(tt, tabM, tabIN, words, L, Lwave, active, sc, plane, tid,      \
-                                   xt, dirty, o, a.dbg_wmask, a.dbg_rowstep)
-                if (first_iter)
-                {
-                    if (first && last) QL_SWEEP(true, true, true);
-                    else if (first) QL_SWEEP(true, false, true);
-                    else if (last) QL_SWEEP(false, true, true);
-                    else QL_SWEEP(false, false, true);
-                }
-                else
-                {
-                    if (first && last) QL_SWEEP(true, true, false);
-                    else if (first) QL_SWEEP(true, false, false);
-                    else if (last) QL_SWEEP(false, true, false);
-                    else QL_SWEEP(false, false, false);
-                }
-#undef QL_SWEEP
+                float4 const *__restrict__ src = reinterpret_cast<float4 const *>(
+                    a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
+                float4 *dst = reinterpret_cast<float4 *>(tabM);
+                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
+                    dst[i] = src[i];
             }
-            first_iter = false;
-            if (!__syncthreads_or(dirty ? 1 : 0)) break;
+            __syncthreads();
+            if (Lwave == 0u) continue; // no lane of this wavefront has a query
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
+            bool const first = t == 0, last = t + 1 == T;
+#define QL_SWEEP(F, L_)                                                                          \
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, \
+                              o, a.dbg_wmask, a.dbg_rowstep)
+            if (first && last) QL_SWEEP(true, true);
+            else if (first) QL_SWEEP(true, false);
+            else if (last) QL_SWEEP(false, true);
+            else QL_SWEEP(false, false);
+#undef QL_SWEEP
         }
 
-        if (has)
+        if (has && dirty)
+        {
+            // B0 was not the solution for this pair: the row-sweep kernel scores it
+            unsigned const cls = pm.cls;
+            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
+            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
+            else *a.redo_overflow = 1u; // host falls back to the row sweep for the whole scan
+        }
+        else if (has)
         {
             float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
             float const nul = o.Rn;
@@ -521,6 +538,22 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
     }
 }
 
+// words_t[wt_off[qb] + w * NT + t] = word w of the query in lane t of block qb (0 past its end)
+template <int NT>
+__global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
+{
+    unsigned const qb = blockIdx.x, tid = threadIdx.x;
+    unsigned const qi = qb * (unsigned)NT + tid;
+    bool const has = qi < a.nseqs;
+    unsigned const q = has ? a.qorder[qi] : 0u;
+    unsigned const nw = has ? a.seq_len[q] / 16u + 3u : 0u; // words the upload packed for q
+    uint32_t const *__restrict__ src = a.seq_words + a.seq_woff[q];
+    unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) / (unsigned)NT;
+    uint32_t *dst = a.words_t + a.wt_off[qb];
+    for (unsigned w = 0; w < rows; ++w)
+        dst[w * (unsigned)NT + tid] = w < nw ? src[w] : 0u;
+}
+
 template <int G, int NT, int D>
 static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 {
@@ -533,6 +566,13 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 // blocks at 3 wavefronts per SIMD (168 VGPRs) spill ~840 registers and run 3x slower.
 extern "C" unsigned dcp_qlane_block_size(void) { return 256u; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
+extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
+
+extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream)
+{
+    hipLaunchKernelGGL((transpose_words_kernel<256>), dim3(a->nqblocks), dim3(256), 0,
+                       (hipStream_t)stream, *a);
+}
 
 extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {

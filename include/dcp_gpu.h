@@ -253,15 +253,25 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *, struct dcp_scan_params const *,
  * buffer. */
 int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *, void *hits_dev, unsigned cap,
                            void *nhits_dev);
-/* Wait for the stream. */
+/* Wait for the stream (and, after a query-lane scan, check its redo lists:
+ * see dcp_gpu_last_scan_redo_pairs). */
 int dcp_gpu_sync(dcp_gpu_ctx *);
+/* Query-lane scans with multi_hits score a pair under B(j) = N(j) + NB and
+ * verify that against the E -> B / J -> B feedback; pairs that fail the check
+ * are re-scored exactly by the row-sweep kernel behind it on the same stream.
+ * Their number in the last scan (0 for row-sweep and uni-hit scans);
+ * synchronises. */
+int dcp_gpu_last_scan_redo_pairs(dcp_gpu_ctx *, unsigned *npairs);
 /* Milliseconds between HIP events recorded on the context's stream around the
  * kernels of the LAST dcp_gpu_scan (valid after dcp_gpu_sync). */
 float dcp_gpu_last_scan_ms(dcp_gpu_ctx *);
-/* Number of DP kernel launches of the last scan (one per profile size class). */
+/* Number of DP kernel launches of the last scan (row sweep: one per profile
+ * size class; query lane: one, plus one redo launch per size class). */
 unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
 /* Launch i of the last scan: its kernel shape, HIP-event duration on the
- * context's stream, DP cells and algorithmic bytes. */
+ * context's stream, DP cells and algorithmic bytes.  The cells
+ * of a query-lane scan are all counted in its launch 0; its redo launches
+ * report 0 cells. */
 struct dcp_launch_info
 {
     int nodes_per_lane; /* row sweep: R; query lane: nodes per tile */

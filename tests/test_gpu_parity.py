@@ -217,6 +217,11 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
     for multi in (True, False):
         scanner.scan(multi, False, 10.0, kernel=kern)
         gn, ga = scanner.scores()
+        # the query-lane kernel hands pairs with E -> B / J -> B feedback (the two-domain query
+        # at least) to the row sweep; uni-hit scans and row-sweep scans have no redo pairs
+        redo = scanner.last_scan_redo_pairs
+        assert (redo >= 1) if (multi and kern == dcp.KERNEL_QLANE) else (redo == 0)
+        assert redo < len(seqs) * len(profiles)
         on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
         assert same_bits(gn, on) and same_bits(ga, oa)
         lrt = np.float32(-2) * (on - oa)
@@ -239,6 +244,33 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
     scanner.scan(False, False, 10.0, kernel=kern)
     a_uni = scanner.scores()[1][9, 3]
     assert a_multi > a_uni
+
+
+def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner, monkeypatch):
+    """More feedback pairs than a redo list holds: the scan is repeated by the row-sweep kernel
+    and stays bit-exact (DCP_REDO_CAP shrinks the lists to one pair per size class)."""
+    rng = np.random.default_rng(33)
+    M = 60
+    prm = pfam_like_params(rng, M)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg)]
+    prof_eps[id(profiles[0])] = cfg.epsilon
+    oprof = oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01)
+    two = lambda: np.concatenate([planted_query(rng, oprof, M), planted_query(rng, oprof, M)])
+    seqs = [two(), two(), two()] + rand_seqs(rng, 5, 100, 300)
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+    assert scanner.last_scan_redo_pairs >= 3
+    gn, ga = scanner.scores()
+    assert same_bits(gn, on) and same_bits(ga, oa)
+    monkeypatch.setenv("DCP_REDO_CAP", "1")
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+    gn, ga = scanner.scores()
+    assert same_bits(gn, on) and same_bits(ga, oa)
+    got = sorted((int(h["seq_idx"]), int(h["profile_idx"])) for h in scanner.hits())
+    assert got[:3] == [(0, 0), (1, 0), (2, 0)]
 
 
 def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
