@@ -59,12 +59,6 @@ __device__ __forceinline__ float mx5(float a, float b, float c, float d, float e
     return mx3(mx3(a, b, c), d, e); // two v_max3_f32
 }
 
-__device__ __forceinline__ unsigned code_of(unsigned w, int l)
-{
-    constexpr unsigned off[5] = {0u, 4u, 20u, 84u, 340u};
-    return off[l - 1] + (w & ((1u << (2 * l)) - 1u));
-}
-
 template <int G> struct QState
 {
     float P[5][4 * G]; // predecessor maxima of M_k leaving row j', slot j' % 5
@@ -171,16 +165,42 @@ __device__ __forceinline__ void ring_fetch(Ring &r, int slot, float const *pB, f
     ring_fetch_b<FIRST>(r, slot, pB, off);
 }
 
-template <int G, bool FIRST, bool LAST>
-__device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float2 const *tabIN, unsigned w)
+// Gather addresses.  Row `code` of a table group is 16 bytes (4 nodes), so the byte offset of
+// the word of length l+1 ending at the window w is  (w * 16 & mask_l * 16) + first_l * 16: one
+// v_and per length on the pre-shifted window, the constant part (and the group's base) folds
+// into the ds_read offset field.  The insert / background table has 8-byte rows: half of it.
+struct GatherOff
 {
+    unsigned a[5]; // (w & (4^(l+1) - 1)) * 16
+};
+__device__ __forceinline__ GatherOff gather_off(unsigned w)
+{
+    unsigned const w16 = w << 4;
+    GatherOff g;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+        g.a[l] = w16 & (((1u << (2 * l + 2)) - 1u) << 4);
+    g.a[4] = w16; // the window is 10 bits: all of it
+    return g;
+}
+template <int GROUP> __device__ __forceinline__ float4 gather_match(float const *tabM, GatherOff const &g, int l)
+{
+    constexpr unsigned first[5] = {0u, 4u, 20u, 84u, 340u};
+    return *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(tabM) +
+                                             (g.a[l] + (first[l] + (unsigned)GROUP * NC) * 16u));
+}
+
+template <int G, bool FIRST, bool LAST>
+__device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float2 const *tabIN, GatherOff const &g)
+{
+    constexpr unsigned first[5] = {0u, 4u, 20u, 84u, 340u};
 #pragma unroll
     for (int l = 0; l < 5; ++l)
     {
-        unsigned const c = code_of(w, l + 1);
-        in.e0[l] = *reinterpret_cast<float4 const *>(tabM + (size_t)c * 4);
+        in.e0[l] = gather_match<0>(tabM, g, l);
         // insert and background emissions of a word sit side by side: one ds_read_b64
-        float2 const v = tabIN[c];
+        float2 const v = *reinterpret_cast<float2 const *>(reinterpret_cast<char const *>(tabIN) +
+                                                           ((g.a[l] >> 1) + first[l] * 8u));
         in.eI[l] = v.x;
         in.eN[l] = v.y;
     }
@@ -196,7 +216,7 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // wn) as soon as group 0 has consumed it.
 template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
-                                       float2 const *tabIN, unsigned w,
+                                       float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned off, LaneXt const &xt,
                                        bool live, bool at_end, bool &dirty, SweepOut &o)
@@ -206,12 +226,15 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     float const ni = ninf();
 
     // gather groups 1.. of this row now; they land while group 0 computes
+    // (`go` = this row's gather offsets, computed when the previous row prefetched group 0)
+    static_assert(G <= 2, "gather_match<GROUP> is instantiated for groups 0 and 1");
     float4 e[G > 1 ? G - 1 : 1][5];
-#pragma unroll
-    for (int g = 1; g < G; ++g)
+    if constexpr (G > 1)
+    {
 #pragma unroll
         for (int l = 0; l < 5; ++l)
-            e[g - 1][l] = *reinterpret_cast<float4 const *>(tabM + ((size_t)g * NC + code_of(w, l + 1)) * 4);
+            e[0][l] = gather_match<1>(tabM, go, l);
+    }
 
     float Xm = ni, Xd = ni, E = ni, Bj = ring.B[PH];
     if constexpr (!FIRST)
@@ -288,7 +311,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     }
 
     // `in` is consumed: refill it for row j+1 while the other groups compute
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, wn);
+    go = gather_off(wn);
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
 
 #pragma unroll
     for (int g = 1; g < G; ++g)
@@ -391,7 +415,8 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         in.e0[l] = float4{ni, ni, ni, ni}, in.eI[l] = ni, in.eN[l] = ni;
         ring.B[l] = ring.Xm[l] = ring.Xd[l] = ring.Em[l] = ni;
     }
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, w);
+    GatherOff go = gather_off(w);
+    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
 #pragma unroll
     for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
         ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT * 4));
@@ -400,10 +425,9 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     {                                                                                      \
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
-        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabIN, w, wn, in, ring, pB, pXm,       \
+        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm,       \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o);                                              \
-        w = wn;                                                                            \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
         wq[PH] = wordsT[((pos + 5u) >> 4) * (unsigned)NT + tid]; /* for row j + 5 */        \
         off += rowstep * 4u;                                                                     \
