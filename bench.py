@@ -219,6 +219,7 @@ def main():
     fence()
     per_class = {}
     kernel_ms = 0.0
+    redo_pairs = 0
     t0 = time.perf_counter()
     for i in range(args.warmup, nsteps):
         step(i)
@@ -229,7 +230,8 @@ def main():
             acc["bytes"] += li["algorithmic_bytes"]
             acc["cells"] += li["cells"]
             acc["launches"] += 1
-            kernel_ms += li["ms"]
+        kernel_ms += sc.last_scan_ms
+        redo_pairs += sc.last_scan_redo_pairs
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -301,7 +303,11 @@ def main():
                 "per_class_ms_per_step": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"): round(v["ms"] / args.steps, 3)
                                           for k, v in sorted(per_class.items())},
                 "per_class_gcells_per_s": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"):
-                                           round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in sorted(per_class.items())},
+                                           round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1)
+                                           for k, v in sorted(per_class.items()) if v["cells"]},
+                # query-lane scans: pairs with multi-hit feedback are re-scored by the row-sweep
+                # launches (R*W* above, overlapping each other after the query-lane kernel)
+                "redo_pairs_per_step": round(redo_pairs / args.steps, 1),
             },
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
         }

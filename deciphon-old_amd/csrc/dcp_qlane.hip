@@ -131,6 +131,10 @@ __device__ __forceinline__ float ld_off(float const *base, unsigned boff)
 {
     return *reinterpret_cast<float const *>(reinterpret_cast<char const *>(base) + boff);
 }
+__device__ __forceinline__ unsigned ld_u32(uint32_t const *base, unsigned boff)
+{
+    return *reinterpret_cast<uint32_t const *>(reinterpret_cast<char const *>(base) + boff);
+}
 __device__ __forceinline__ void st_off(float *base, unsigned boff, float v)
 {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + boff) = v;
@@ -218,7 +222,7 @@ template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
-                                       float *pXd, float *pEm, unsigned off, LaneXt const &xt,
+                                       float *pXd, float *pEm, unsigned &off, LaneXt const &xt,
                                        bool live, bool at_end, bool &dirty, SweepOut &o)
 {
     constexpr int KT = 4 * G;
@@ -304,10 +308,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // allocator gives the new value another register and copies it into place at the loop's
     // back edge, and that copy waits for a load issued half a row earlier.  (B is in use
     // until the last node: its slot is refilled at the end of the row.)
+    // (The row offset D rows ahead is folded into the plane pointers; the asm works on `off`
+    // itself, so no copy of it is made.)
+    if constexpr (!FIRST)
     {
-        unsigned roff = off + (unsigned)(D * NT * 4);
-        asm volatile("" : "+v"(roff) : "v"(E));
-        ring_fetch_x<FIRST>(ring, (PH + D) % 5, pXm, pXd, pEm, roff);
+        asm volatile("" : "+v"(off) : "v"(E));
+        ring_fetch_x<FIRST>(ring, (PH + D) % 5, pXm + D * NT, pXd + D * NT, pEm + D * NT, off);
     }
 
     // `in` is consumed: refill it for row j+1 while the other groups compute
@@ -324,10 +330,10 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         node(4 * g + 3, eg[0].w, eg[1].w, eg[2].w, eg[3].w, eg[4].w);
     }
 
+    if constexpr (!kRecomputeB && !FIRST)
     {
-        unsigned roff = off + (unsigned)(D * NT * 4);
-        asm volatile("" : "+v"(roff) : "v"(pm));
-        ring_fetch_b<FIRST>(ring, (PH + D) % 5, pB, roff);
+        asm volatile("" : "+v"(off) : "v"(pm));
+        ring_fetch_b<FIRST>(ring, (PH + D) % 5, pB + D * NT, off);
     }
 
     if constexpr (!LAST)
@@ -403,6 +409,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
     // phi copy and costs a vmcnt(0) drain each time.)
     unsigned j = 1;
+    unsigned const tid4 = tid * 4u;
     unsigned const w0 = wordsT[tid];
     unsigned wq[5] = {w0, w0, w0, w0, w0}; // rows 1..5 take bases 2..6: all in word 0
     unsigned w = w0 & 3u & wmask;
@@ -429,7 +436,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o);                                              \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
-        wq[PH] = wordsT[((pos + 5u) >> 4) * (unsigned)NT + tid]; /* for row j + 5 */        \
+        wq[PH] = ld_u32(wordsT + ((pos + 5u) >> 4) * (unsigned)NT, tid4); /* for row j + 5 */ \
         off += rowstep * 4u;                                                                     \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
@@ -491,7 +498,8 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
         bool const has = qi < a.nseqs;
         unsigned const q = has ? a.qorder[qi] : 0u;
         unsigned const L = has ? a.seq_len[q] : 0u;
-        uint32_t const *__restrict__ wordsT = a.words_t + a.wt_off[qb]; // wave-uniform
+        // wave-uniform (readfirstlane: the compiler cannot see that through the load)
+        uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
         LaneXt xt;
         {
             float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
