@@ -273,6 +273,34 @@ def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner, monk
     assert got[:3] == [(0, 0), (1, 0), (2, 0)]
 
 
+@pytest.mark.parametrize("M", [300, 600, 1300, 2600])
+def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
+    """A real hit against a big profile leaves the query-lane kernel through the redo list of a
+    multi-wavefront size class (W = 2, 4, 8, 16): the row sweep's pair mode must score it, and every
+    other pair of the scan, bit-exactly."""
+    rng = np.random.default_rng(M + 1)
+    prm = pfam_like_params(rng, M)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    small = pfam_like_params(rng, 37)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg), dcp.ProteinProfile.from_params(*small, cfg)]
+    for p in profiles:
+        prof_eps[id(p)] = cfg.epsilon
+    oprof = oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01)
+    seqs = rand_seqs(rng, 6, 50, 400)
+    seqs[1] = planted_query(rng, oprof, M, flank=12)
+    seqs[4] = planted_query(rng, oracle32.new(*small, ENTRY_DIST_OCCUPANCY, 0.01), 37, flank=40)
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+    assert scanner.last_scan_redo_pairs >= 2
+    assert scanner.last_scan_launches >= 3  # query lane + one redo launch per populated size class
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    assert same_bits(gn, on) and same_bits(ga, oa)
+    got = {(int(h["seq_idx"]), int(h["profile_idx"])) for h in scanner.hits()}
+    assert {(1, 0), (4, 1)} <= got
+
+
 def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
     """Size-independent properties: same scores on re-scan, under profile permutation and
     when the batch is split (pairs are independent)."""
