@@ -240,6 +240,11 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
             e[0][l] = gather_match<1>(tabM, go, l);
     }
 
+    // one counted wait for the whole prefetched `in` (the five group-1 gathers just issued stay in
+    // flight) instead of the compiler's wait before every use: an s_waitcnt costs an issue slot
+    if constexpr (G > 1) __builtin_amdgcn_s_waitcnt(0xC07F | (5 << 8)); // lgkmcnt(5)
+    else __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8));
+    __builtin_amdgcn_sched_barrier(0); // keep the gathers above: the scheduler would sink them to their use
     float Xm = ni, Xd = ni, E = ni, Bj = ring.B[PH];
     if constexpr (!FIRST)
     {
@@ -317,6 +322,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     }
 
     // `in` is consumed: refill it for row j+1 while the other groups compute
+    // group 1's gathers (issued at the top of the row) are the only LDS reads in flight: one wait
+    __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); // lgkmcnt(0)
     go = gather_off(wn);
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
 
