@@ -242,8 +242,16 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
     // one counted wait for the whole prefetched `in` (the five group-1 gathers just issued stay in
     // flight) instead of the compiler's wait before every use: an s_waitcnt costs an issue slot
-    if constexpr (G > 1) __builtin_amdgcn_s_waitcnt(0xC07F | (5 << 8)); // lgkmcnt(5)
-    else __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8));
+    // The same s_waitcnt covers what this row takes from global memory -- its ring slot and its
+    // sequence word, both issued five rows ago: everything but the VMEM operations of the four
+    // rows in between (loads and stores count alike, in issue order).
+    {
+        constexpr int per_row = (FIRST ? 0 : 3) + (LAST ? 0 : 3) + ((!kRecomputeB && !FIRST) ? 1 : 0) +
+                                ((!kRecomputeB && FIRST) ? 1 : 0) + 1;
+        constexpr int vm = 4 * per_row; // <= 32
+        constexpr int lgkm = G > 1 ? 5 : 0;
+        __builtin_amdgcn_s_waitcnt((vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8));
+    }
     __builtin_amdgcn_sched_barrier(0); // keep the gathers above: the scheduler would sink them to their use
     float Xm = ni, Xd = ni, E = ni, Bj = ring.B[PH];
     if constexpr (!FIRST)
