@@ -130,6 +130,10 @@ struct dcp_gpu_ctx
     unsigned ext_cap = 0;
     // one HIP event after each size-class launch of the last scan
     hipEvent_t ev_class[kNumClasses + 1] = {nullptr};
+    // small row-sweep scans (the reference's one-sequence-at-a-time mode) are bound by the latency
+    // of one pair's row chain, not by throughput: their size-class launches run side by side
+    hipStream_t class_stream[kNumClasses] = {nullptr};
+    bool last_overlapped = false;
     int launched_class[kNumClasses + 1] = {0};
     unsigned n_launched = 0;
 
@@ -195,6 +199,8 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
     bool ok = true;
     for (int k = 0; k <= kNumClasses; ++k)
         ok = ok && hipEventCreate(&c->ev_class[k]) == hipSuccess;
+    for (int k = 0; k < kNumClasses; ++k)
+        ok = ok && hipStreamCreateWithFlags(&c->class_stream[k], hipStreamNonBlocking) == hipSuccess;
     if (!ok)
     {
         fprintf(stderr, "dcp_gpu: failed to create stream/events on device %d\n", device);
@@ -213,6 +219,8 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (int k = 0; k <= kNumClasses; ++k)
         if (c->ev_class[k]) (void)hipEventDestroy(c->ev_class[k]);
+    for (int k = 0; k < kNumClasses; ++k)
+        if (c->class_stream[k]) (void)hipStreamDestroy(c->class_stream[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -711,7 +719,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         char const *f = getenv("DCP_KERNEL");
         if (f && !strcmp(f, "rowsweep")) kernel = 1;
         else if (f && !strcmp(f, "qlane")) kernel = 2;
-        else kernel = nq >= 128 ? 2 : 1;
+        else kernel = nq >= 48 ? 2 : 1; // measured crossover on the C3 DB (profiles/latency_probe.py)
         // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
         if (kernel == 2)
         {
@@ -887,10 +895,15 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->redo_pending = false;
     c->last_redo_pairs = 0;
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    // fork / join around the class launches when no single one fills the chip
+    bool const overlap = (uint64_t)nq * c->nprof < ((uint64_t)1 << 21);
+    c->last_overlapped = overlap;
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
         if (last <= first) continue;
+        hipStream_t const ls = overlap ? c->class_stream[k] : c->stream;
+        if (overlap) HIP_TRY(c, hipStreamWaitEvent(ls, c->ev_start, 0));
         a.first_prof = first;
         a.nprof = last - first;
         SizeClass const sc = kClasses[k];
@@ -899,9 +912,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t nblocks = (ntasks + tpb - 1) / tpb;
         nblocks = (nblocks + 7) / 8 * 8;
         if (ntasks > 0xffffffffull || nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
-        if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, c->stream))
+        if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, ls))
             return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
-        HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
+        if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_class[c->n_launched], 0));
         c->launched_class[c->n_launched++] = k;
         c->last_launches++;
     }
@@ -966,7 +980,8 @@ int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_
     if (!c || !out || !c->scanned) return DCP_EINVAL;
     if (i >= c->n_launched) return DCP_EINVAL;
     int const k = c->launched_class[i];
-    hipEvent_t const before = i == 0 ? c->ev_start : c->ev_class[i - 1];
+    // overlapped row-sweep launches all start at ev_start
+    hipEvent_t const before = i == 0 || (c->last_kernel == 1 && c->last_overlapped) ? c->ev_start : c->ev_class[i - 1];
     if (hipEventSynchronize(c->ev_class[i]) != hipSuccess) return DCP_EFAIL;
     float ms = 0;
     if (hipEventElapsedTime(&ms, before, c->ev_class[i]) != hipSuccess) return DCP_EFAIL;

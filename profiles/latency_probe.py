@@ -1,0 +1,31 @@
+"""Small-batch scan latency on the C3 DB (the reference scans one sequence at a time: scan.c:227-258)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+dcp = bench.load_product()
+sizes = bench.core_sizes_for("c3", 20000)
+cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+from concurrent.futures import ThreadPoolExecutor
+with ThreadPoolExecutor(16) as ex:
+    profs = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"), range(20000)))
+sc = dcp.Scanner(0)
+sc.upload_db(profs)
+del profs
+q = bench.make_queries(0, 256, 1000)
+off = (np.arange(257, dtype=np.uint64) * 1000).astype(np.uint32)
+sc.upload_seqs_flat(q.reshape(-1), off)
+cellsM = int(sizes.sum())
+for kname, kern in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE)):
+    for nq in (1, 2, 4, 16, 32, 48, 64, 96, 128, 256):
+        if kname == "rowsweep" and nq > 64 or kname == "qlane" and nq < 16:
+            continue
+        for rep in range(2):
+            t = time.perf_counter()
+            sc.scan(True, False, 10.0, keep_scores=False, sync=True, q_range=(0, nq), kernel=kern)
+            dt = time.perf_counter() - t
+        print(f"{kname:8s} nq={nq:4d} wall {dt*1e3:8.2f} ms  kernel {sc.last_scan_ms:8.2f} ms  launches {sc.last_scan_launches}  "
+              f"{cellsM*nq*1000/dt/1e9:7.1f} Gcell/s", flush=True)
+        if nq == 1 and kname == "auto":
+            print("   per size class (ms since scan start):",
+                  {f"R{li['R']}W{li['W']}": (round(li["ms"], 2), li["nprofiles"]) for li in sc.launch_infos()}, flush=True)
