@@ -29,3 +29,14 @@ for kname, kern in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP)
         if nq == 1 and kname == "auto":
             print("   per size class (ms since scan start):",
                   {f"R{li['R']}W{li['W']}": (round(li["ms"], 2), li["nprofiles"]) for li in sc.launch_infos()}, flush=True)
+
+# one sequence at a time, as scan.c:227-258 drives thread_run: upload + scan + fetch hits per sequence
+for i in range(6):
+    t0 = time.perf_counter()
+    sc.upload_seqs([q[i]])
+    t1 = time.perf_counter()
+    sc.scan(True, False, 10.0, keep_scores=False, sync=True)
+    t2 = time.perf_counter()
+    h = sc.hits()
+    t3 = time.perf_counter()
+    print(f"per-sequence loop {i}: upload {1e3*(t1-t0):6.2f} ms  scan {1e3*(t2-t1):6.2f} ms (kernel {sc.last_scan_ms:6.2f})  hits {1e3*(t3-t2):5.2f} ms  n={len(h)}", flush=True)
