@@ -295,6 +295,32 @@ int profile_typeid(struct profile const *prof) { return prof->vtable.typeid; }
 struct imm_dp const *profile_null_dp(struct profile const *prof) { return prof->vtable.null_dp(prof); }
 struct imm_dp const *profile_alt_dp(struct profile const *prof) { return prof->vtable.alt_dp(prof); }
 
+/* ---- standard_profile: typed shell (src/model/standard_profile.c:45-51, standard_state.c:5-10) --- */
+static void standard_del(struct profile *prof) { (void)prof; }
+static struct imm_dp const *standard_null_dp(struct profile const *prof)
+{
+    return &((struct standard_profile const *)prof)->dp.null;
+}
+static struct imm_dp const *standard_alt_dp(struct profile const *prof)
+{
+    return &((struct standard_profile const *)prof)->dp.alt;
+}
+unsigned standard_state_name(unsigned id, char name[IMM_STATE_NAME_SIZE])
+{
+    assert(id <= UINT16_MAX);
+    return (unsigned)snprintf(name, IMM_STATE_NAME_SIZE, "S%u", id);
+}
+void standard_profile_init(struct standard_profile *p, char const *accession, struct imm_nuclt_code const *code)
+{
+    memset(p, 0, sizeof *p);
+    p->super.vtable = (struct profile_vtable){PROFILE_STANDARD, standard_del, standard_null_dp, standard_alt_dp};
+    snprintf(p->super.accession, sizeof p->super.accession, "%s", accession ? accession : "");
+    p->super.state_name = standard_state_name;
+    p->super.code = code;
+    p->dp.null = (struct imm_dp){NULL, 1};
+    p->dp.alt = (struct imm_dp){NULL, 0};
+}
+
 void protein_profile_init(struct protein_profile *p, char const *accession, struct imm_amino const *amino,
                           struct imm_nuclt_code const *code, struct protein_cfg cfg)
 {

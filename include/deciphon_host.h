@@ -268,6 +268,25 @@ struct protein_profile
     bool multi_hits, hmmer3_compat;
 };
 
+/* include/deciphon/model/standard_profile.h:10-23, standard_state.h:6: the generic (non-protein)
+ * profile is just two imm_dp.  It is dead in the reference's scan path -- profile_reader_setup
+ * accepts PROFILE_PROTEIN only (src/db/profile_reader.c:95-98) and the union member is commented
+ * out (include/deciphon/db/profile_reader.h:18) -- so it is kept as the typed shell the API
+ * promises: init, typeid, state names.  Its imm_dp hold no model: imm_dp_viterbi on them fails.
+ * (standard_profile_pack writes lite_pack, which is outside this path.) */
+struct standard_profile
+{
+    struct profile super;
+    struct
+    {
+        struct imm_dp null;
+        struct imm_dp alt;
+    } dp;
+};
+void standard_profile_init(struct standard_profile *prof, char const *accession,
+                           struct imm_nuclt_code const *code);
+unsigned standard_state_name(unsigned id, char name[IMM_STATE_NAME_SIZE]);
+
 void protein_profile_init(struct protein_profile *prof, char const *accession,
                           struct imm_amino const *amino, struct imm_nuclt_code const *code,
                           struct protein_cfg cfg);

@@ -318,8 +318,38 @@ static void scan_run_batched(void)
         profile_del(&profs[p].super);
 }
 
+/* test/standard_profile.c:5-31 is a smoke test (no numeric golden): a standard profile is a typed
+ * shell around two imm_dp, and the scan path never takes one (profile_reader.c:95-98) */
+static void standard_profile_shell(void)
+{
+    struct imm_nuclt const *nuclt = &imm_dna_iupac;
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, nuclt);
+    struct standard_profile prof;
+    standard_profile_init(&prof, "accession", &code);
+    CHECK(profile_typeid(&prof.super) == PROFILE_STANDARD);
+    CHECK(strcmp(profile_typeid_name(PROFILE_STANDARD), "standard") == 0);
+    CHECK(strcmp(prof.super.accession, "accession") == 0);
+    CHECK(profile_null_dp(&prof.super) == &prof.dp.null);
+    CHECK(profile_alt_dp(&prof.super) == &prof.dp.alt);
+    char name[IMM_STATE_NAME_SIZE];
+    CHECK(prof.super.state_name(513, name) == 4);
+    CHECK(strcmp(name, "S513") == 0);
+    /* no model behind its dps: scoring is refused, not faked */
+    struct imm_seq seq = imm_seq(IMM_STR(query), prof.super.code->abc);
+    struct imm_task *task = imm_task_new(&prof.dp.alt);
+    struct imm_prod prod = imm_prod();
+    CHECK(task != NULL);
+    CHECK(imm_task_setup(task, &seq) == IMM_OK);
+    CHECK(imm_dp_viterbi(&prof.dp.alt, task, &prod) != IMM_OK);
+    imm_task_del(task);
+    imm_prod_del(&prod);
+    profile_del(&prof.super);
+}
+
 int main(void)
 {
+    standard_profile_shell();
     golden_profile(ENTRY_DIST_UNIFORM, -55.59428153448);
     golden_profile(ENTRY_DIST_OCCUPANCY, -54.35543421312);
     scan_threads();
