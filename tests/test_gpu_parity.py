@@ -301,6 +301,28 @@ def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
     assert {(1, 0), (4, 1)} <= got
 
 
+def test_kernel_choice_by_batch_size(dcp, scanner):
+    """kernel = 0: row sweep below 48 queries (latency path, the reference's one-sequence mode), the
+    query-lane kernel from 48 on; both agree bit for bit where the ranges meet."""
+    rng = np.random.default_rng(48)
+    profiles = make_profiles(dcp, [(900 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((3, 70, 130, 300))])
+    seqs = rand_seqs(rng, 60, 20, 120)
+    scanner.upload_db(profiles)
+    scanner.upload_seqs(seqs)
+    with pytest.raises(dcp.DcpError):
+        dcp.Scanner(0).last_scan_redo_pairs  # no scan yet
+    scanner.scan(True, False, 10.0, q_range=(0, 47))
+    assert all(li["W"] >= 1 for li in scanner.launch_infos())       # row-sweep launches only
+    assert scanner.last_scan_redo_pairs == 0
+    n47, a47 = scanner.scores()
+    scanner.scan(True, False, 10.0, q_range=(0, 48))
+    infos = scanner.launch_infos()
+    assert infos[0]["W"] == 0 and infos[0]["cells"] == sum(p.core_size for p in profiles) * sum(len(s) for s in seqs[:48])
+    assert all(li["cells"] == 0 for li in infos[1:])                 # redo launches carry no cells of their own
+    n48, a48 = scanner.scores()
+    assert same_bits(n47[:47], n48[:47]) and same_bits(a47[:47], a48[:47])
+
+
 def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
     """Size-independent properties: same scores on re-scan, under profile permutation and
     when the batch is split (pairs are independent)."""
