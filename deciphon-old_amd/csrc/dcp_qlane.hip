@@ -7,7 +7,7 @@
 // the 5-row history of its KT nodes in registers; what the next tile needs from
 // row j -- D of its first node, the M/I/D part of that node's predecessor
 // maximum, the running E -- goes through per-block scratch planes in HBM
-// (coalesced, 28 B per row and tile).  No cross-lane operation exists: the
+// (coalesced, 12 B read + 12 B written per row, tile and lane).  No cross-lane operation exists: the
 // delete chain is sequential in k inside the lane.
 //
 // Multi-hit feedback (B(j) needs E(j) of the same row, which needs every tile):
@@ -16,7 +16,7 @@
 // never does, B0 IS the solution of the recurrence (a forward recurrence in j, so
 // its solution is unique) and the lane's scores are exact -- bit-identical to the
 // row sweep of dcp_kernels.hip and to the oracle.  A lane where it does (a pair
-// with a local match good enough to re-enter the core: ~0.2 % of random pairs)
+// with a local match good enough to re-enter the core: 1 % of the C3 pairs)
 // publishes nothing and appends its (query, profile) to the redo list of the
 // profile's size class; the row-sweep kernel, which has the whole row in one
 // wavefront group and therefore the exact B(j), scores those pairs right after
@@ -121,7 +121,7 @@ struct RowIn
     float eI[5], eN[5];
 };
 
-// Boundary values of the previous tile (and the B in use), fetched FIVE rows
+// Boundary values of the previous tile, fetched FIVE rows
 // ahead into a register ring indexed by j % 5: a row's compute time (~0.6 us) is
 // shorter than loaded-HBM latency, and with two waves per SIMD a late load stalls
 // the SIMD.
