@@ -472,3 +472,50 @@ def test_long_sequences(dcp, oracle32, scanner, kern):
     assert same_bits(gn, on)
     assert same_bits(ga, oa)
     assert np.isfinite(ga).all()
+
+
+def test_full_size_c3_step_both_kernels_agree(dcp, oracle32):
+    """BASELINE.json's headline size: one bench step = 20 000 profiles (sum M = 3.57e6) x 1 000 queries of
+    1 000 nt = 2e7 pairs, 3.6e12 cells.  Too big for the oracle, so a size-independent property: the two
+    independent device implementations (row sweep, query lane + redo) agree bit for bit on every one of the
+    2e7 null and alt scores and on the hit list, and a few sampled pairs are checked against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from concurrent.futures import ThreadPoolExecutor
+
+    sizes = bench.core_sizes_for("c3", 20000)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    with ThreadPoolExecutor(16) as ex:
+        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
+                               range(len(sizes))))
+    queries = bench.make_queries(0, 1000, 1000)
+    sc = dcp.Scanner(0)
+    try:
+        sc.upload_db(profiles)
+        del profiles
+        sc.upload_seqs_flat(queries.reshape(-1), (np.arange(1001, dtype=np.uint64) * 1000).astype(np.uint32))
+        out = {}
+        for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
+            sc.scan(True, False, 10.0, kernel=k)
+            n, a = sc.scores()
+            out[name] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
+            if name == "qlane":
+                redo = sc.last_scan_redo_pairs
+        assert 0 < redo < 0.05 * 2e7
+        assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
+        assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
+        assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
+        assert np.isfinite(out["qlane"][1].view(np.float32)).all()
+        rng = np.random.default_rng(7)
+        alt = out["qlane"][1].view(np.float32)
+        nul = out["qlane"][0].view(np.float32)
+        for _ in range(6):
+            q, p = int(rng.integers(0, 1000)), int(rng.integers(0, 20000))
+            op = oracle32.sample(0xDEC1F0 + p, int(sizes[p]))
+            assert op.setup(1000, True, False) == 0
+            _, on, oa = op.viterbi_fast(bytes(queries[q]))
+            assert abs(nul[q, p] - on) <= REL * abs(on) and abs(alt[q, p] - oa) <= REL * abs(oa)
+    finally:
+        sc.close()
