@@ -519,3 +519,38 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32):
             assert abs(nul[q, p] - on) <= REL * abs(on) and abs(alt[q, p] - oa) <= REL * abs(oa)
     finally:
         sc.close()
+
+
+def test_mixed_length_stress_both_kernels_agree(dcp):
+    """BASELINE.json configs[4] shape at a size both kernels finish in seconds: 2 000 profiles with
+    M log-uniform on 50..2000 x 600 queries log-uniform on 100..10 000 nt (length-sorted blocks, a partial
+    last block, every size class up to W = 8).  Row sweep and query lane + redo must agree bit for bit on
+    all 1.2e6 pairs and on the hits."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from concurrent.futures import ThreadPoolExecutor
+
+    sizes = bench.core_sizes_for("c5", 2000)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    with ThreadPoolExecutor(16) as ex:
+        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg), range(len(sizes))))
+    queries = bench.make_queries(0, 600, 0)
+    assert min(len(q) for q in queries) < 150 and max(len(q) for q in queries) > 8000
+    sc = dcp.Scanner(0)
+    try:
+        sc.upload_db(profiles)
+        del profiles
+        sc.upload_seqs(queries)
+        out = {}
+        for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
+            sc.scan(True, False, 10.0, kernel=k)
+            n, a = sc.scores()
+            out[name] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
+        assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
+        assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
+        assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
+        assert np.isfinite(out["qlane"][1].view(np.float32)).all()
+    finally:
+        sc.close()
