@@ -824,7 +824,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             if (int rc = ensure_rowsweep_layout(c)) return rc;
             a.emis_match = c->d_emis_match.p;
             uint64_t tot = 0;
-            uint64_t cap_limit = 1u << 24; // per size class; DCP_REDO_CAP: tests of the overflow path
+            uint64_t cap_limit = 1u << 26; // per size class (512 MB of pairs at most); DCP_REDO_CAP: tests of the overflow path
             if (char const *e = getenv("DCP_REDO_CAP")) cap_limit = (uint64_t)std::max(1, atoi(e));
             for (int k = 0; k < kNumClasses; ++k)
             {
@@ -926,7 +926,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
 }
 
 // Wait for the stream; after a query-lane scan also look at the redo counters.  A redo list
-// that overflowed (> 2^24 pairs of one size class needed the row sweep) lost pairs: the scan is
+// that overflowed (> 2^26 pairs of one size class needed the row sweep) lost pairs: the scan is
 // repeated with the row-sweep kernel, which needs no list.
 static int finish_scan(dcp_gpu_ctx *c)
 {
