@@ -611,18 +611,21 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 // SGPRs), 256 queries per block at 2 wavefronts per SIMD, boundary ring 5 rows deep.
 // Measured alternatives: KT = 12 spills at the 256-VGPR cap; 384-thread
 // blocks at 3 wavefronts per SIMD (168 VGPRs) spill ~840 registers and run 3x slower.
-extern "C" unsigned dcp_qlane_block_size(void) { return 256u; }
+#ifndef DCP_QLANE_NT
+#define DCP_QLANE_NT 256
+#endif
+extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 
 extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream)
 {
-    hipLaunchKernelGGL((transpose_words_kernel<256>), dim3(a->nqblocks), dim3(256), 0,
+    hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0,
                        (hipStream_t)stream, *a);
 }
 
 extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    launch_ql<2, 256, 5>(a, nblocks, (hipStream_t)stream);
+    launch_ql<2, DCP_QLANE_NT, 5>(a, nblocks, (hipStream_t)stream);
     return 0;
 }
