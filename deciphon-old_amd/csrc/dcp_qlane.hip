@@ -248,7 +248,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     {
         constexpr int per_row = (FIRST ? 0 : 3) + (LAST ? 0 : 3) + ((!kRecomputeB && !FIRST) ? 1 : 0) +
                                 ((!kRecomputeB && FIRST) ? 1 : 0) + 1;
-        constexpr int vm = 4 * per_row; // <= 32
+        constexpr int vm = (D - 1) * per_row; // <= 32 (the sequence words are always five rows ahead)
         constexpr int lgkm = G > 1 ? 5 : 0;
         __builtin_amdgcn_s_waitcnt((vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8));
     }
@@ -614,6 +614,9 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 #ifndef DCP_QLANE_NT
 #define DCP_QLANE_NT 256
 #endif
+#ifndef DCP_QLANE_D
+#define DCP_QLANE_D 5 // rows of boundary prefetch (1..5)
+#endif
 extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
@@ -626,6 +629,6 @@ extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream
 
 extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    launch_ql<2, DCP_QLANE_NT, 5>(a, nblocks, (hipStream_t)stream);
+    launch_ql<2, DCP_QLANE_NT, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
     return 0;
 }
