@@ -334,6 +334,10 @@ def main():
                 # 256 CU x 128 lanes x 2.4 GHz = 78.6e12 lane-ops/s (= 157.3 TFLOPS / 2)
                 "valu": {"ops_per_cell": 28, "peak_ops": 78.6e12,
                          "frac": round(dom["cells"] / (dom["ms"] * 1e-3) * 28 / 78.6e12, 4)},
+                # where the query-lane kernel reads those algorithmic bytes from: LDS gathers, 256 B/clk/CU
+                # x 256 CUs x 2.4 GHz = 157 TB/s conflict-free (random 16-byte gathers serialise ~2.1x)
+                "lds": ({"bytes_per_cell": 20, "peak": 157286.0, "unit": "GB/s",
+                         "frac": round(dom["cells"] / (dom["ms"] * 1e-3) * 20 / 157.286e12, 4)} if not dom_key[1] else None),
                 "avg_launch_ms": round(dom_ms, 3),
                 "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
                 "all_kernels_achieved": round(all_gbs, 1),
