@@ -80,6 +80,30 @@ def test_reads_profiles_like_from_params(dcp, tmp_path):
     assert np.isneginf(profs[0].trans8[4:6, 0]).all()
 
 
+def test_pfam_style_file_features(dcp, tmp_path):
+    """What a Pfam-A.hmm written by HMMER 3.1b2 carries beyond the minimum: DATE/GA/TC/NC/BM/SM lines,
+    three STATS lines, and five annotation columns (MAP CONS RF MM CS) after each match line.  No real
+    Pfam file is available here (a network download in the reference's tests), so the features are
+    added to a synthetic model and must not change what is read."""
+    import re
+    rng = np.random.default_rng(31)
+    match, trans, cons = random_model(rng, 9)
+    plain, pfam = str(tmp_path / "plain.hmm"), str(tmp_path / "pfam.hmm")
+    write_hmm(plain, [("1-cysPrx_C", "PF10417.8", match, trans, cons)])
+    s = open(plain).read()
+    s = s.replace("MAP   yes\n", "MAP   yes\nDATE  Wed Sep 26 13:22:24 2018\n")
+    s = s.replace("CKSUM 1\n", "CKSUM 2692542929\nGA    21.10 21.10;\nTC    21.10 21.10;\nNC    21.00 21.00;\n"
+                  "BM    hmmbuild HMM.ann SEED.ann\nSM    hmmsearch -Z 45638612 -E 1000 --cpu 4 HMM pfamseq\n")
+    s = s.replace("STATS LOCAL MSV       -9.0  0.7\n", "STATS LOCAL MSV       -7.4458  0.71858\n"
+                  "STATS LOCAL VITERBI   -7.6857  0.71858\nSTATS LOCAL FORWARD   -3.8142  0.71858\n")
+    s = re.sub(r"(\d+) (\w) - - -\n", r"\1 \2 - - H\n", s)
+    open(pfam, "w").write(s)
+    a, b = dcp.read_hmmer3(plain)[0], dcp.read_hmmer3(pfam)[0]
+    assert b.accession == "PF10417.8" and b.core_size == 9 and b.consensus == a.consensus
+    assert np.array_equal(a.match_dist, b.match_dist) and np.array_equal(a.trans8, b.trans8)
+    assert np.array_equal(a.null_dist, b.null_dist)
+
+
 @pytest.mark.parametrize("breakage,rc_name", [
     (lambda s: s.replace("ALPH  amino", "ALPH  DNA"), "RC_EPARSE"),
     (lambda s: s.replace("HMMER3/f", "HMMER2.0"), "RC_EPARSE"),
