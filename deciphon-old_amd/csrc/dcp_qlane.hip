@@ -40,6 +40,10 @@ constexpr int NC = DCP_NCODES;
 #define DCP_QLANE_RECOMPUTE_B 1
 #endif
 constexpr bool kRecomputeB = DCP_QLANE_RECOMPUTE_B != 0;
+#ifndef DCP_QLANE_WD
+#define DCP_QLANE_WD 5 // rows of sequence-word prefetch (1..5)
+#endif
+constexpr unsigned kWD = DCP_QLANE_WD;
 constexpr unsigned kPlanes = kRecomputeB ? 3u : 4u; // scratch planes per block: Xm, Xd, Em (, B0)
 
 // Read-only tables are accessed through the constant address space: the data
@@ -121,7 +125,7 @@ struct RowIn
     float eI[5], eN[5];
 };
 
-// Boundary values of the previous tile, fetched FIVE rows
+// Boundary values of the previous tile, fetched D (= 3) rows
 // ahead into a register ring indexed by j % 5: a row's compute time (~0.6 us) is
 // shorter than loaded-HBM latency, and with two waves per SIMD a late load stalls
 // the SIMD.
@@ -243,12 +247,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // one counted wait for the whole prefetched `in` (the five group-1 gathers just issued stay in
     // flight) instead of the compiler's wait before every use: an s_waitcnt costs an issue slot
     // The same s_waitcnt covers what this row takes from global memory -- its ring slot and its
-    // sequence word, both issued five rows ago: everything but the VMEM operations of the four
+    // sequence word, issued D and five rows ago: everything but the VMEM operations of the D - 1
     // rows in between (loads and stores count alike, in issue order).
     {
         constexpr int per_row = (FIRST ? 0 : 3) + (LAST ? 0 : 3) + ((!kRecomputeB && !FIRST) ? 1 : 0) +
                                 ((!kRecomputeB && FIRST) ? 1 : 0) + 1;
-        constexpr int vm = (D - 1) * per_row; // <= 32 (the sequence words are always five rows ahead)
+        constexpr int vm = ((D < (int)kWD ? D : (int)kWD) - 1) * per_row; // <= 32
         constexpr int lgkm = G > 1 ? 5 : 0;
         __builtin_amdgcn_s_waitcnt((vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8));
     }
@@ -451,7 +455,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o);                                              \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
-        wq[PH] = ld_u32(wordsT + ((pos + 5u) >> 4) * (unsigned)NT, tid4); /* for row j + 5 */ \
+        wq[(PH + kWD) % 5] = ld_u32(wordsT + ((pos + kWD) >> 4) * (unsigned)NT, tid4); /* row j + kWD */ \
         off += rowstep * 4u;                                                                     \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
@@ -608,14 +612,14 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 }
 
 // One configuration is built: KT = 8 nodes per tile (G = 2: the tile's transitions fit in
-// SGPRs), 256 queries per block at 2 wavefronts per SIMD, boundary ring 5 rows deep.
+// SGPRs), 256 queries per block at 2 wavefronts per SIMD, boundary prefetch 3 rows deep.
 // Measured alternatives: KT = 12 spills at the 256-VGPR cap; 384-thread
 // blocks at 3 wavefronts per SIMD (168 VGPRs) spill ~840 registers and run 3x slower.
 #ifndef DCP_QLANE_NT
 #define DCP_QLANE_NT 256
 #endif
 #ifndef DCP_QLANE_D
-#define DCP_QLANE_D 5 // rows of boundary prefetch (1..5)
+#define DCP_QLANE_D 3 // rows of boundary prefetch (1..5); measured 1: -30 %, 2: -1 %, 3: best, 4: -0.3 %, 5: -0.7 %
 #endif
 extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
