@@ -90,6 +90,8 @@ struct dcp_gpu_ctx
     // query-lane kernel layout (dcp_qlane.hip)
     int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
     std::vector<dcp_ql_prof> ql_metas; // same order as metas
+    uint64_t sum_core = 0, sum_tiles = 0; // over the resident DB (kernel choice)
+    unsigned max_tiles = 0;
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
@@ -326,6 +328,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     unsigned const KT = 4u * (unsigned)c->ql_G;
     uint64_t tile_floats = 0, ttrans_floats = 0;
     c->ql_metas.assign(nprofiles, dcp_ql_prof{});
+    c->sum_core = c->sum_tiles = 0;
+    c->max_tiles = 0;
     for (unsigned i = 0; i < nprofiles; ++i)
     {
         dcp_prof_meta const &m = c->metas[i];
@@ -335,6 +339,9 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         qm.rs_slot = i; // ql_metas and metas share one order
         qm.cls = (uint32_t)class_of(m.core_size);
         qm.ntiles = (m.core_size + KT - 1) / KT;
+        c->sum_core += m.core_size;
+        c->sum_tiles += qm.ntiles;
+        c->max_tiles = std::max(c->max_tiles, qm.ntiles);
         qm.tile_off = tile_floats;
         qm.ttrans_off = (uint32_t)ttrans_floats;
         tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
@@ -547,6 +554,7 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
     if (!seqs || !seq_off || nseqs == 0) return c->fail(DCP_EINVAL, "empty sequence batch");
     HIP_TRY(c, hipSetDevice(c->device));
     c->scanned = false;
+    c->qorder_q0 = c->qorder_q1 = ~0u; // also when this upload fails half way
     std::vector<uint32_t> woff(nseqs), len(nseqs);
     uint64_t nwords = 0, total = 0;
     for (unsigned q = 0; q < nseqs; ++q)
@@ -595,6 +603,8 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
     c->nseqs = nseqs;
     c->total_len = total;
     c->xt_multi = c->xt_h3 = -1;
+    // the length order and the transposed word planes belong to the batch that was resident
+    c->qorder_q0 = c->qorder_q1 = ~0u;
     return DCP_OK;
 }
 
@@ -719,13 +729,34 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         char const *f = getenv("DCP_KERNEL");
         if (f && !strcmp(f, "rowsweep")) kernel = 1;
         else if (f && !strcmp(f, "qlane")) kernel = 2;
-        else kernel = nq >= 48 ? 2 : 1; // measured crossover on the C3 DB (profiles/latency_probe.py)
-        // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
-        if (kernel == 2)
+        else
         {
-            unsigned lmax = 0;
-            for (unsigned q = q_begin; q < q_end; ++q)
-                lmax = std::max(lmax, c->seq_len[q]);
+            // Cost model fitted to profiles/latency_probe.py and profiles/smalldb_probe.py (it picks
+            // the faster kernel in all 26 measured (DB size, batch size) points):
+            //   row sweep    cells / 340 Gcell/s
+            //   query lane   max(longest task, all tile rows / resident blocks); a tile row of a block
+            //                takes 0.52 us with one busy wavefront, 0.73 us with four.
+            // On the 20k-profile DB the switch comes at 45 queries; a DB of a few hundred profiles
+            // stays with the row sweep up to several hundred queries (its tasks cannot fill the grid).
+            unsigned const NTq = dcp_qlane_block_size();
+            std::vector<unsigned> len(c->seq_len.begin() + q_begin, c->seq_len.begin() + q_end);
+            std::sort(len.begin(), len.end());
+            double sum_len = 0, sum_block_lmax = 0;
+            for (unsigned L : len)
+                sum_len += L;
+            unsigned const nqb = (nq + NTq - 1u) / NTq;
+            for (unsigned b = 0; b < nqb; ++b)
+                sum_block_lmax += len[std::min(nq, (b + 1u) * NTq) - 1u];
+            unsigned const lmax = len.back();
+            double const t_rs = std::max((double)c->sum_core * sum_len / 340e9, lmax * 1.6e-6); // or one pair's row chain
+            unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
+            double const trow = (0.52 + 0.07 * (waves - 1u)) * 1e-6;
+            double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, 2ull * c->num_cus);
+            double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
+                                         (double)c->sum_tiles * sum_block_lmax * trow / resident) +
+                                1e-4; // its redo launches
+            kernel = t_ql < t_rs ? 2 : 1;
+            // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
             if (lmax > 200000u) kernel = 1;
         }
     }

@@ -224,7 +224,7 @@ struct dcp_scan_params
     int hmmer3_compat;   /* scan_thread.h:18 */
     float lrt_threshold; /* scan.c:221 passes 10.0 */
     int keep_scores;     /* also keep dense null/alt score matrices */
-    int kernel;          /* 0 = choose by batch size; 1 = row sweep (one wavefront
+    int kernel;          /* 0 = choose by a cost model (DB size x batch size); 1 = row sweep (one wavefront
                           * group per pair: any batch size); 2 = query lane (one
                           * lane per query, tiles in LDS: throughput path) */
 };

@@ -302,8 +302,10 @@ def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
 
 
 def test_kernel_choice_by_batch_size(dcp, scanner):
-    """kernel = 0: row sweep below 48 queries (latency path, the reference's one-sequence mode), the
-    query-lane kernel from 48 on; both agree bit for bit where the ranges meet."""
+    """kernel = 0 picks by a cost model: a DB of a few profiles cannot fill the query-lane kernel's
+    persistent grid, so it stays with the row sweep at any batch size (the 20k-profile DB switches to the
+    query-lane kernel at 45 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
+    gives the same bits; launch infos tell the two apart."""
     rng = np.random.default_rng(48)
     profiles = make_profiles(dcp, [(900 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((3, 70, 130, 300))])
     seqs = rand_seqs(rng, 60, 20, 120)
@@ -311,16 +313,44 @@ def test_kernel_choice_by_batch_size(dcp, scanner):
     scanner.upload_seqs(seqs)
     with pytest.raises(dcp.DcpError):
         dcp.Scanner(0).last_scan_redo_pairs  # no scan yet
-    scanner.scan(True, False, 10.0, q_range=(0, 47))
+    scanner.scan(True, False, 10.0)
     assert all(li["W"] >= 1 for li in scanner.launch_infos())       # row-sweep launches only
     assert scanner.last_scan_redo_pairs == 0
-    n47, a47 = scanner.scores()
-    scanner.scan(True, False, 10.0, q_range=(0, 48))
+    n_auto, a_auto = scanner.scores()
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
     infos = scanner.launch_infos()
-    assert infos[0]["W"] == 0 and infos[0]["cells"] == sum(p.core_size for p in profiles) * sum(len(s) for s in seqs[:48])
+    assert infos[0]["W"] == 0 and infos[0]["cells"] == sum(p.core_size for p in profiles) * sum(len(s) for s in seqs)
     assert all(li["cells"] == 0 for li in infos[1:])                 # redo launches carry no cells of their own
-    n48, a48 = scanner.scores()
-    assert same_bits(n47[:47], n48[:47]) and same_bits(a47[:47], a48[:47])
+    n_ql, a_ql = scanner.scores()
+    assert same_bits(n_auto, n_ql) and same_bits(a_auto, a_ql)
+
+
+def test_new_batch_of_equal_count_is_not_scanned_with_the_old_one_s_layout(dcp, scanner):
+    """The query-lane kernel keeps a per-range length order and transposed word planes; a new upload with
+    the same number of sequences (other lengths, other bases) must rebuild them -- regression test for a
+    stale cache that read the previous batch's planes."""
+    rng = np.random.default_rng(606)
+    profiles = make_profiles(dcp, [(700 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((9, 40, 77))])
+    scanner.upload_db(profiles)
+    a = rand_seqs(rng, 12, 20, 60)
+    b = rand_seqs(rng, 12, 200, 900)  # longer: the old planes would be too small
+    scanner.upload_seqs(a)
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+    for batch in (b, a, b):
+        scanner.upload_seqs(batch)
+        scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+        nq, aq = scanner.scores()
+        scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+        nr, ar = scanner.scores()
+        assert same_bits(nq, nr) and same_bits(aq, ar)
+    with pytest.raises(dcp.DcpError):
+        scanner.upload_seqs([np.array([0, 1, 7, 2], np.uint8)] * 12)  # a failed upload keeps nothing half-built
+    scanner.upload_seqs(a)
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+    n2, a2 = scanner.scores()
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+    n3, a3 = scanner.scores()
+    assert same_bits(n2, n3) and same_bits(a2, a3)
 
 
 def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
@@ -504,6 +534,11 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32):
             if name == "qlane":
                 redo = sc.last_scan_redo_pairs
         assert 0 < redo < 0.05 * 2e7
+        # kernel = 0 on this DB: the query-lane kernel from 45 queries on, the row sweep below
+        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 64))
+        assert sc.launch_infos()[0]["W"] == 0
+        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 32))
+        assert sc.launch_infos()[0]["W"] >= 1
         assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
         assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
         assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
