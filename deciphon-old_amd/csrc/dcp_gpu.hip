@@ -243,6 +243,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     if (nprofiles > (1u << 20)) return c->fail(DCP_EINVAL, "too many profiles"); // MAX_NPROFILES limits.h:7
     HIP_TRY(c, hipSetDevice(c->device));
     c->scanned = false;
+    c->redo_pending = false;
 
     // classify and order: by size class, then by caller index
     std::vector<int> cls(nprofiles);
@@ -554,6 +555,7 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
     if (!seqs || !seq_off || nseqs == 0) return c->fail(DCP_EINVAL, "empty sequence batch");
     HIP_TRY(c, hipSetDevice(c->device));
     c->scanned = false;
+    c->redo_pending = false;           // the previous batch's scan is void
     c->qorder_q0 = c->qorder_q1 = ~0u; // also when this upload fails half way
     std::vector<uint32_t> woff(nseqs), len(nseqs);
     uint64_t nwords = 0, total = 0;
