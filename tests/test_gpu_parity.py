@@ -353,6 +353,49 @@ def test_new_batch_of_equal_count_is_not_scanned_with_the_old_one_s_layout(dcp, 
     assert same_bits(n2, n3) and same_bits(a2, a3)
 
 
+def test_random_api_sequences(dcp, scanner):
+    """State-machine stress: random interleavings of DB uploads, sequence uploads (sometimes invalid),
+    ranged / full scans, flag changes and kernel choices.  After every scan the other kernel must reproduce
+    the scores bit for bit on the same range, and the hit lists must match."""
+    rng = np.random.default_rng(20261004)
+    cfg_specs = lambda n: [(int(rng.integers(1, 1 << 20)), int(rng.integers(1, 400)), ENTRY_DIST_OCCUPANCY, 0.01) for _ in range(n)]
+    profiles = make_profiles(dcp, cfg_specs(5))
+    scanner.upload_db(profiles)
+    seqs = rand_seqs(rng, 7, 5, 300)
+    scanner.upload_seqs(seqs)
+    nscans = 0
+    for step in range(40):
+        op = rng.integers(0, 10)
+        if op == 0:
+            profiles = make_profiles(dcp, cfg_specs(int(rng.integers(1, 9))))
+            scanner.upload_db(profiles)
+        elif op in (1, 2):
+            n = len(seqs) if op == 2 else int(rng.integers(1, 70))   # op 2: same count, new content
+            seqs = rand_seqs(rng, n, 1, int(rng.choice([40, 300, 1500])))
+            scanner.upload_seqs(seqs)
+        elif op == 3:
+            with pytest.raises(dcp.DcpError):
+                scanner.upload_seqs([np.array([0, 9], np.uint8)])
+        else:
+            n = len(seqs)
+            lo = int(rng.integers(0, n))
+            hi = int(rng.integers(lo + 1, n + 1))
+            q_range = None if rng.random() < 0.4 else (lo, hi)
+            multi, h3 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            first = [dcp.KERNEL_QLANE, dcp.KERNEL_ROWSWEEP, dcp.KERNEL_AUTO][int(rng.integers(0, 3))]
+            other = dcp.KERNEL_ROWSWEEP if first == dcp.KERNEL_QLANE else dcp.KERNEL_QLANE
+            sl = slice(0, n) if q_range is None else slice(lo, hi)
+            res = []
+            for k in (first, other):
+                scanner.scan(multi, h3, 10.0, kernel=k, q_range=q_range)
+                nn, aa = scanner.scores()
+                res.append((nn[sl].copy(), aa[sl].copy(), scanner.hits()))
+            assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1]), (step, q_range, multi, h3)
+            assert np.array_equal(res[0][2], res[1][2])
+            nscans += 1
+    assert nscans >= 15
+
+
 def test_scan_is_idempotent_and_order_free(dcp, scanner, kern):
     """Size-independent properties: same scores on re-scan, under profile permutation and
     when the batch is split (pairs are independent)."""
