@@ -1,0 +1,120 @@
+// Mutation fuzzer for the two file formats next to the scan path: the HMMER3 ASCII reader
+// (dcp_h3reader_*) and the dcpx profile DB (dcp_db_*).  Built with -fsanitize=address,undefined
+// by tests/test_sanitizers.py: every mutated file must end in DCP_OK / DCP_END or a clean error
+// code -- never a crash, an out-of-bounds access or a leak.
+//   fuzz_parsers good.hmm good.dcpx scratch_dir iterations seed
+#include "dcp_gpu.h"
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+static uint64_t rng_state;
+static uint64_t rnd()
+{
+    rng_state ^= rng_state << 13, rng_state ^= rng_state >> 7, rng_state ^= rng_state << 17;
+    return rng_state;
+}
+
+static std::vector<unsigned char> slurp(char const *path)
+{
+    std::vector<unsigned char> b;
+    if (FILE *f = std::fopen(path, "rb"))
+    {
+        unsigned char buf[4096];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0)
+            b.insert(b.end(), buf, buf + n);
+        std::fclose(f);
+    }
+    return b;
+}
+
+static void mutate(std::vector<unsigned char> &b, bool text)
+{
+    unsigned const nmut = 1 + (unsigned)(rnd() % 4);
+    for (unsigned m = 0; m < nmut && !b.empty(); ++m)
+    {
+        size_t const at = rnd() % b.size();
+        switch (rnd() % 5)
+        {
+        case 0: b[at] = text ? (unsigned char)" \n*.-0123456789eEHMLN/"[rnd() % 22] : (unsigned char)rnd(); break;
+        case 1: b.resize(at); break;                                         // truncate
+        case 2: b.insert(b.begin() + at, b.begin() + at, b.begin() + std::min(b.size(), at + 1 + rnd() % 64)); break; // duplicate a run
+        case 3: b.erase(b.begin() + at, b.begin() + std::min(b.size(), at + 1 + rnd() % 64)); break;
+        default: b[at] ^= (unsigned char)(1u << (rnd() % 8)); break;          // bit flip
+        }
+    }
+}
+
+static bool dump(std::string const &path, std::vector<unsigned char> const &b)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    if (!b.empty()) std::fwrite(b.data(), 1, b.size(), f);
+    std::fclose(f);
+    return true;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) return 2;
+    std::vector<unsigned char> const hmm = slurp(argv[1]), dbf = slurp(argv[2]);
+    std::string const dir = argv[3];
+    unsigned const iters = (unsigned)std::atoi(argv[4]);
+    rng_state = 0x9E3779B97F4A7C15ull ^ (uint64_t)std::atoll(argv[5]);
+    if (hmm.empty() || dbf.empty()) return 2;
+    unsigned ok_hmm = 0, ok_db = 0;
+    for (unsigned it = 0; it < iters; ++it)
+    {
+        {
+            std::vector<unsigned char> b = hmm;
+            mutate(b, true);
+            std::string const p = dir + "/m.hmm";
+            if (!dump(p, b)) return 3;
+            dcp_h3reader *r = dcp_h3reader_open(p.c_str(), DCP_ENTRY_DIST_OCCUPANCY, 0.01f);
+            if (r)
+            {
+                dcp_profile *prof = nullptr;
+                int rc;
+                unsigned n = 0;
+                while ((rc = dcp_h3reader_next(r, &prof)) == DCP_OK && n < 64)
+                {
+                    if (!prof || dcp_profile_core_size(prof) == 0) return 4;
+                    dcp_profile_del(prof);
+                    ++n;
+                }
+                if (rc == DCP_END) ++ok_hmm;
+                else if (rc != DCP_OK && !dcp_h3reader_error(r)) return 5; // an error must carry a message
+                dcp_h3reader_close(r);
+            }
+        }
+        {
+            std::vector<unsigned char> b = dbf;
+            mutate(b, false);
+            std::string const p = dir + "/m.dcpx";
+            if (!dump(p, b)) return 3;
+            int rc = -1;
+            dcp_db *db = dcp_db_open(p.c_str(), &rc);
+            if (db)
+            {
+                unsigned const n = dcp_db_nprofiles(db);
+                uint32_t const *sz = dcp_db_profile_sizes(db);
+                for (unsigned i = 0; i < n; ++i)
+                    if (sz[i] == 0) return 7;
+                unsigned psize[DCP_NUM_THREADS];
+                int64_t poff[DCP_NUM_THREADS + 1];
+                (void)dcp_db_partitions(db, 1 + (unsigned)(rnd() % DCP_NUM_THREADS), psize, poff);
+                std::vector<dcp_profile *> out(n, nullptr);
+                if (n && dcp_db_read(db, 0, n, out.data()) == DCP_OK) ++ok_db;
+                for (dcp_profile *q : out)
+                    dcp_profile_del(q);
+                dcp_db_close(db);
+            }
+            else if (rc == DCP_OK) return 6; // a failed open must say why
+        }
+    }
+    std::printf("fuzz_parsers ok: %u iterations, %u hmm and %u dcpx mutants still parsed\n", iters, ok_hmm, ok_db);
+    return 0;
+}

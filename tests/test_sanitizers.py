@@ -32,3 +32,27 @@ def test_host_model_under_asan_ubsan(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "asan_host_model ok" in r.stdout
+
+
+def test_file_parsers_survive_mutation_fuzzing_under_asan_ubsan(dcp, tmp_path):
+    """tests/c/fuzz_parsers.cpp: thousands of mutated HMMER3 and dcpx files (byte edits, bit flips,
+    truncations, duplicated and deleted runs) through dcp_h3reader_* / dcp_db_* under ASan + UBSan +
+    LeakSanitizer: clean error codes only."""
+    from test_h3reader import random_model, write_hmm
+
+    rng = np.random.default_rng(5)
+    hmm, dbx = tmp_path / "good.hmm", tmp_path / "good.dcpx"
+    write_hmm(hmm, [("a", "PF1.1", *random_model(rng, 3)), ("b", "", *random_model(rng, 17))])
+    dcp.write_db(str(dbx), dcp.read_hmmer3(str(hmm)))
+    exe = str(tmp_path / "fuzz_parsers")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "deciphon-old_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "fuzz_parsers.cpp"),
+                           os.path.join(ROOT, "deciphon-old_amd", "csrc", "dcp_model.cpp"), "-o", exe])
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    r = subprocess.run([exe, str(hmm), str(dbx), str(scratch), "4000", "20261004"], capture_output=True, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fuzz_parsers ok" in r.stdout
