@@ -232,8 +232,12 @@ dcp_profile *dcp_profile_new(char const *accession, unsigned core_size,
     p->entry_dist = entry_dist;
     p->epsilon = epsilon;
     p->consensus.assign(M + 1, '\0');
+    bool ended = !consensus; // a consensus shorter than the core is padded, never read past its NUL
     for (unsigned i = 0; i < M; ++i)
-        p->consensus[i] = consensus ? consensus[i] : '-';
+    {
+        if (!ended && consensus[i] == '\0') ended = true;
+        p->consensus[i] = ended ? '-' : consensus[i];
+    }
 
     // protein_model_init: null dist from the null amino lprobs, insert dist from
     // all-zero log-odds (protein_model.c:122-127)

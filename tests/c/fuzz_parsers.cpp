@@ -115,6 +115,46 @@ int main(int argc, char **argv)
             else if (rc == DCP_OK) return 6; // a failed open must say why
         }
     }
-    std::printf("fuzz_parsers ok: %u iterations, %u hmm and %u dcpx mutants still parsed\n", iters, ok_hmm, ok_db);
+    // the model builder with hostile parameters: -inf / NaN / huge log-probabilities, edge core sizes,
+    // bad entry_dist / epsilon, missing consensus -- a profile or DCP_EINVAL, and a finite-or--inf table
+    unsigned built = 0;
+    for (unsigned it = 0; it < iters / 8 + 8; ++it)
+    {
+        static unsigned const sizes[] = {0, 1, 2, 3, 64, 65, 257, 4096, 4097};
+        unsigned const M = sizes[rnd() % 9];
+        size_t const Mm = M ? M : 1;
+        auto val = [&]() -> float {
+            switch (rnd() % 12)
+            {
+            case 0: return -__builtin_inff();
+            case 1: return __builtin_nanf("");
+            case 2: return 1e30f;
+            case 3: return -1e30f;
+            case 4: return 0.0f;
+            default: return -(float)(rnd() % 100000) / 10000.0f;
+            }
+        };
+        std::vector<float> nul(20), mat(Mm * 20), tr((Mm + 1) * 7);
+        for (float &v : nul) v = val();
+        for (float &v : mat) v = val();
+        for (float &v : tr) v = val();
+        int const entry = (int)(rnd() % 5) - 1;
+        float const eps = (rnd() % 4 == 0) ? val() : 0.01f;
+        std::string const cons(rnd() % 3 ? Mm : Mm / 2, 'a');
+        int rc = -77;
+        dcp_profile *p = dcp_profile_new(rnd() % 5 ? "acc" : nullptr, M, entry, eps, nul.data(), mat.data(), tr.data(),
+                                         rnd() % 4 ? cons.c_str() : nullptr, &rc);
+        if (!p && rc == DCP_OK) return 8;
+        if (p)
+        {
+            if (M == 0 || M > 4096) return 9;
+            float tab[DCP_NCODES];
+            dcp_frame_table_host(dcp_profile_match_dist(p) + (size_t)(M - 1) * DCP_NDIST, 0.01f, tab);
+            ++built;
+            dcp_profile_del(p);
+        }
+    }
+    std::printf("fuzz_parsers ok: %u iterations, %u hmm and %u dcpx mutants still parsed, %u hostile profiles built\n", iters,
+                ok_hmm, ok_db, built);
     return 0;
 }
