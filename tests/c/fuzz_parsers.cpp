@@ -154,7 +154,39 @@ int main(int argc, char **argv)
             dcp_profile_del(p);
         }
     }
-    std::printf("fuzz_parsers ok: %u iterations, %u hmm and %u dcpx mutants still parsed, %u hostile profiles built\n", iters,
-                ok_hmm, ok_db, built);
+    // decode and product rows with hostile inputs: symbols outside ACGT, fragment lengths 0..8, state ids
+    // of nodes the profile does not have, steps that run past the sequence, tiny output buffers
+    unsigned rows = 0;
+    {
+        int rc = -1;
+        dcp_profile *p = dcp_profile_sample("acc", 11, 9, DCP_ENTRY_DIST_OCCUPANCY, 0.01f, &rc);
+        if (!p) return 10;
+        for (unsigned it = 0; it < iters; ++it)
+        {
+            uint8_t seq[40], codon[3];
+            unsigned const L = (unsigned)(rnd() % 41);
+            for (unsigned i = 0; i < L; ++i)
+                seq[i] = (uint8_t)(rnd() % 16 ? rnd() % 4 : rnd());
+            unsigned const sid = (unsigned)(rnd() % 8 ? ((rnd() % 4) << 14) | (rnd() % 12) : rnd() & 0xffff);
+            (void)dcp_profile_decode(p, seq, (unsigned)(rnd() % 9), sid, codon);
+            dcp_step steps[24];
+            unsigned const ns = (unsigned)(rnd() % 25);
+            for (unsigned i = 0; i < ns; ++i)
+                steps[i] = dcp_step{(uint16_t)(rnd() % 6 ? ((rnd() % 4) << 14) | (rnd() % 11) : rnd()), (uint8_t)(rnd() % 7), 0};
+            char row[600];
+            size_t const cap = rnd() % 5 ? sizeof row : (size_t)(rnd() % 64);
+            long const n = dcp_prod_format_row(row, cap, (int64_t)rnd(), -3, rnd() % 7 ? "PF00001.1" : "", "dna", -1.5, -2.5,
+                                               "protein", "0.1.0", p, seq, L, steps, ns);
+            if (n > (long)cap) return 11;
+            if (n > 0)
+            {
+                if (row[n - 1] != '\n') return 12;
+                ++rows;
+            }
+        }
+        dcp_profile_del(p);
+    }
+    std::printf("fuzz_parsers ok: %u iterations, %u hmm and %u dcpx mutants still parsed, %u hostile profiles built, %u rows\n", iters,
+                ok_hmm, ok_db, built, rows);
     return 0;
 }
