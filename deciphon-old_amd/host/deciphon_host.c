@@ -415,6 +415,7 @@ enum rc protein_codec_next(struct protein_codec *codec, struct imm_seq const *se
         codec->idx++;
     }
     if (codec->idx >= imm_path_nsteps(codec->path)) return RC_END;
+    if (codec->start + step->seqlen > imm_seq_size(seq)) return fail(RC_EINVAL, "path does not fit the sequence");
     struct imm_seq frag = imm_subseq(seq, codec->start, step->seqlen);
     codec->start += step->seqlen;
     codec->idx++;
