@@ -353,6 +353,26 @@ def test_new_batch_of_equal_count_is_not_scanned_with_the_old_one_s_layout(dcp, 
     assert same_bits(n2, n3) and same_bits(a2, a3)
 
 
+def test_smallest_profiles(dcp, oracle32, scanner, kern):
+    """core_size 1, 2 and 3 (protein_model_setup accepts 1..4096, protein_model.c:157-160): no I state at
+    all for one node, D_1 without an incoming edge; queries of 1 to 20 nt."""
+    rng = np.random.default_rng(123)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = []
+    for M in (1, 2, 3, 1):
+        p = dcp.ProteinProfile.from_params(*pfam_like_params(rng, M), cfg)
+        prof_eps[id(p)] = cfg.epsilon
+        profiles.append(p)
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 2, 3, 4, 5, 6, 7, 11, 20)]
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    for multi in (True, False):
+        scanner.scan(multi, False, 10.0, kernel=kern)
+        gn, ga = scanner.scores()
+        on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
+        assert same_bits(gn, on) and same_bits(ga, oa)
+
+
 def test_random_api_sequences(dcp, scanner):
     """State-machine stress: random interleavings of DB uploads, sequence uploads (sometimes invalid),
     ranged / full scans, flag changes and kernel choices.  After every scan the other kernel must reproduce
