@@ -107,6 +107,7 @@ struct dcp_gpu_ctx
     unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
     unsigned num_cus = 0;
     int last_kernel = 0; // 1 row sweep, 2 query lane
+    unsigned redo_cap_limit = 1u << 26; // dcp_gpu_test_set_redo_cap
     float last_ql_ms = 0;
 
     // resident sequences
@@ -193,6 +194,9 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         delete c;
         return nullptr;
     }
+    if (dcp_qlane_diag_build())
+        fprintf(stderr, "dcp_gpu: WARNING: this library is a -DDCP_QLANE_DIAG=%u timing build; its scores are WRONG\n",
+                dcp_qlane_diag_build());
     {
         hipDeviceProp_t prop;
         c->num_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? (unsigned)prop.multiProcessorCount : 256u;
@@ -594,6 +598,10 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
             w[i >> 4] |= b << ((i & 15u) * 2u);
         }
     }
+    // a failed (re)allocation below must not leave the old batch's size paired with new buffers
+    c->nseqs = 0;
+    c->total_len = 0;
+    c->seq_len.clear();
     HIP_TRY(c, c->d_seq_words.alloc(nwords));
     HIP_TRY(c, c->d_seq_woff.alloc(nseqs));
     HIP_TRY(c, c->d_seq_len.alloc(nseqs));
@@ -623,6 +631,7 @@ int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *c, char const *text, uint32_t const *s
 // ---------------------------------------------------------------------------
 // Scan
 // ---------------------------------------------------------------------------
+static int finish_scan(dcp_gpu_ctx *c);
 // protein_profile_setup once per sequence (length) instead of once per pair
 static int ensure_xtrans(dcp_gpu_ctx *c, int multi_hits, int hmmer3_compat)
 {
@@ -674,6 +683,11 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (c->nseqs == 0) return c->fail(DCP_EINVAL, "no sequences resident");
     if (q_begin >= q_end || q_end > c->nseqs) return c->fail(DCP_EINVAL, "bad sequence range");
     HIP_TRY(c, hipSetDevice(c->device));
+    // One scan is outstanding per context: results (hits, scores, redo lists) are those of the LAST
+    // scan.  A scan enqueued while the previous one still has unchecked redo lists first completes
+    // that one (its overflow re-run included), so nothing of it is silently half done.
+    if (c->redo_pending)
+        if (int rc = finish_scan(c)) return rc;
 
     if (int rc = ensure_xtrans(c, prm->multi_hits, prm->hmmer3_compat)) return rc;
 
@@ -728,10 +742,6 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     int kernel = prm->kernel;
     if (kernel == 0)
     {
-        char const *f = getenv("DCP_KERNEL");
-        if (f && !strcmp(f, "rowsweep")) kernel = 1;
-        else if (f && !strcmp(f, "qlane")) kernel = 2;
-        else
         {
             // Cost model fitted to profiles/latency_probe.py and profiles/smalldb_probe.py (it picks
             // the faster kernel in all 26 measured (DB size, batch size) points):
@@ -838,13 +848,6 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.lmax = c->qorder_lmax;
         unsigned const NT = dcp_qlane_block_size();
         qa.nqblocks = (nq + NT - 1u) / NT;
-        qa.dbg_wmask = 1023u;
-        qa.dbg_rowstep = NT;
-        if (char const *d = getenv("DCP_QLANE_DEBUG"))
-        {
-            if (atoi(d) & 1) qa.dbg_wmask = 0u;
-            if (atoi(d) & 2) qa.dbg_rowstep = 0u;
-        }
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
@@ -857,8 +860,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             if (int rc = ensure_rowsweep_layout(c)) return rc;
             a.emis_match = c->d_emis_match.p;
             uint64_t tot = 0;
-            uint64_t cap_limit = 1u << 26; // per size class (512 MB of pairs at most); DCP_REDO_CAP: tests of the overflow path
-            if (char const *e = getenv("DCP_REDO_CAP")) cap_limit = (uint64_t)std::max(1, atoi(e));
+            uint64_t const cap_limit = c->redo_cap_limit; // per size class (2^26: 512 MB of pairs at most)
             for (int k = 0; k < kNumClasses; ++k)
             {
                 uint64_t const pairs = (uint64_t)nq * (c->class_first[k + 1] - c->class_first[k]);
@@ -977,6 +979,13 @@ static int finish_scan(dcp_gpu_ctx *c)
     prm.kernel = 1;
     if (int rc = dcp_gpu_scan_range(c, &prm, c->last_q0, c->last_q1)) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCP_OK;
+}
+
+int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)
+{
+    if (!c) return DCP_EINVAL;
+    c->redo_cap_limit = cap ? cap : 1u << 26;
     return DCP_OK;
 }
 

@@ -144,11 +144,6 @@ struct dcp_qlane_args
     unsigned lmax;     // longest resident sequence of this scan
     unsigned ntasks;   // nprof * nqblocks
     unsigned nqblocks; // ceil(nseqs / queries per block)
-    // timing diagnostics (DCP_QLANE_DEBUG; results are wrong when set): window mask 1023 ->
-    // 0 makes every lane gather table row 0 (no LDS bank conflicts); row step 256 -> 0
-    // collapses the scratch planes to one row (no HBM traffic)
-    unsigned dbg_wmask;
-    unsigned dbg_rowstep;
 };
 
 struct dcp_expand_args
@@ -172,6 +167,7 @@ void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);
 unsigned dcp_qlane_scratch_planes(void);
+unsigned dcp_qlane_diag_build(void); // != 0: a -DDCP_QLANE_DIAG timing build (wrong results)
 #ifdef __cplusplus
 }
 #endif

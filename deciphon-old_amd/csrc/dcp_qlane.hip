@@ -45,6 +45,14 @@ constexpr bool kRecomputeB = DCP_QLANE_RECOMPUTE_B != 0;
 #endif
 constexpr unsigned kWD = DCP_QLANE_WD;
 constexpr unsigned kPlanes = kRecomputeB ? 3u : 4u; // scratch planes per block: Xm, Xd, Em (, B0)
+// Timing diagnostics exist only as a separate COMPILE-TIME build (-DDCP_QLANE_DIAG=1|2|3, results are
+// wrong): bit 0 makes every lane gather table row 0 (no LDS bank conflicts), bit 1 collapses the
+// scratch planes to one row (no HBM traffic).  The shipped library is built without it; nothing at
+// run time (no argument, no environment variable) can switch it on.
+#ifndef DCP_QLANE_DIAG
+#define DCP_QLANE_DIAG 0
+#endif
+constexpr unsigned kWMask = (DCP_QLANE_DIAG & 1) ? 0u : 1023u;
 
 // Read-only tables are accessed through the constant address space: the data
 // never changes during the kernel, and loads at wave-uniform addresses then
@@ -386,9 +394,11 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
                                          uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
-                                         SweepOut &o, unsigned wmask, unsigned rowstep)
+                                         SweepOut &o)
 {
     constexpr int KT = 4 * G;
+    constexpr unsigned wmask = kWMask;
+    constexpr unsigned rowstep = (DCP_QLANE_DIAG & 2) ? 0u : (unsigned)NT;
     float const ni = ninf();
     TileTrans<G> tr;
     load_tile_trans<G>(tr, tt);
@@ -555,8 +565,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
 #define QL_SWEEP(F, L_)                                                                          \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, \
-                              o, a.dbg_wmask, a.dbg_rowstep)
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o)
             if (first && last) QL_SWEEP(true, true);
             else if (first) QL_SWEEP(true, false);
             else if (last) QL_SWEEP(false, true);
@@ -625,6 +634,7 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
+extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
 
 extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream)
 {

@@ -241,7 +241,9 @@ struct dcp_hit
 /* Enqueue the scan of all resident sequences against all resident profiles on
  * the context's stream (asynchronous). */
 int dcp_gpu_scan(dcp_gpu_ctx *, struct dcp_scan_params const *);
-/* Same for the resident sequences [q_begin, q_end): scan.c:227-258 hands
+/* One scan is outstanding per context: results are those of the last scan enqueued; enqueueing
+ * another one first completes the previous (it does not queue behind unread results).
+ * Same for the resident sequences [q_begin, q_end): scan.c:227-258 hands
  * thread_run one sequence at a time; a caller that prefetched N sequences scans
  * them batch by batch without re-uploading. Hits and scores keep the indices
  * of the resident batch. */
@@ -253,6 +255,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *, struct dcp_scan_params const *,
  * buffer. */
 int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *, void *hits_dev, unsigned cap,
                            void *nhits_dev);
+/* TEST-ONLY: shrink the per-size-class capacity of the redo lists (default 2^26 pairs; 0 restores
+ * it) so a test can reach the overflow path.  Results are unaffected: an overflowed scan is
+ * repeated with the row-sweep kernel. */
+int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *, unsigned cap);
 /* Wait for the stream (and, after a query-lane scan, check its redo lists:
  * see dcp_gpu_last_scan_redo_pairs). */
 int dcp_gpu_sync(dcp_gpu_ctx *);

@@ -723,9 +723,9 @@ unsigned orc_profile_nstates(struct orc_profile const *p, int alt)
     return (unsigned)(alt ? p->alt.nstates : p->null.nstates);
 }
 
-/* protein_profile_setup: protein_profile.c:155-216 */
-int orc_profile_setup(struct orc_profile *p, unsigned seq_size, int multi_hits,
-                      int hmmer3_compat)
+/* protein_profile_setup: protein_profile.c:155-216.  The 13 values it writes, in the order
+ * RR, SB, SN, NN, NB, ET, EC, CC, CT, EB, EJ, JJ, JB. */
+int orc_xtrans(unsigned seq_size, int multi_hits, int hmmer3_compat, ofloat xt[13])
 {
     if (seq_size == 0) return ORC_EINVAL;
     ofloat L = (ofloat)seq_size;
@@ -748,21 +748,41 @@ int orc_profile_setup(struct orc_profile *p, unsigned seq_size, int multi_hits,
     EJ = log_q;
     EC = (ofloat)O_LOG(1 - q);
     if (hmmer3_compat) NN = CC = JJ = 0;
+    xt[0] = RR;
+    xt[1] = NB;      /* S->B */
+    xt[2] = NN;      /* S->N */
+    xt[3] = NN;      /* N->N */
+    xt[4] = NB;      /* N->B */
+    xt[5] = EC + CT; /* E->T */
+    xt[6] = EC + CC; /* E->C */
+    xt[7] = CC;      /* C->C */
+    xt[8] = CT;      /* C->T */
+    xt[9] = EJ + JB; /* E->B */
+    xt[10] = EJ + JJ; /* E->J */
+    xt[11] = JJ;     /* J->J */
+    xt[12] = JB;     /* J->B */
+    return ORC_OK;
+}
 
-    p->null.trans[p->t_RR].lp = RR;
+int orc_profile_setup(struct orc_profile *p, unsigned seq_size, int multi_hits,
+                      int hmmer3_compat)
+{
+    ofloat xt[13];
+    if (orc_xtrans(seq_size, multi_hits, hmmer3_compat, xt)) return ORC_EINVAL;
+    p->null.trans[p->t_RR].lp = xt[0];
     struct otrans *t = p->alt.trans;
-    t[p->t_SB].lp = NB;
-    t[p->t_SN].lp = NN;
-    t[p->t_NN].lp = NN;
-    t[p->t_NB].lp = NB;
-    t[p->t_ET].lp = EC + CT;
-    t[p->t_EC].lp = EC + CC;
-    t[p->t_CC].lp = CC;
-    t[p->t_CT].lp = CT;
-    t[p->t_EB].lp = EJ + JB;
-    t[p->t_EJ].lp = EJ + JJ;
-    t[p->t_JJ].lp = JJ;
-    t[p->t_JB].lp = JB;
+    t[p->t_SB].lp = xt[1];
+    t[p->t_SN].lp = xt[2];
+    t[p->t_NN].lp = xt[3];
+    t[p->t_NB].lp = xt[4];
+    t[p->t_ET].lp = xt[5];
+    t[p->t_EC].lp = xt[6];
+    t[p->t_CC].lp = xt[7];
+    t[p->t_CT].lp = xt[8];
+    t[p->t_EB].lp = xt[9];
+    t[p->t_EJ].lp = xt[10];
+    t[p->t_JJ].lp = xt[11];
+    t[p->t_JB].lp = xt[12];
     return ORC_OK;
 }
 
@@ -1310,5 +1330,189 @@ long orc_scan(struct orc_profile *const *profiles, unsigned nprofiles,
             }
         }
     }
+    return hits;
+}
+
+/* ======================================================================== */
+/* Optimised CPU variant (SURVEY.md 8d "second CPU figure"): DB resident in   */
+/* RAM, tables exported ONCE per profile, null score once per (sequence,      */
+/* distinct null table), no allocation inside the pair loop, no barrier per   */
+/* sequence: each partition's thread runs its profiles over all sequences.    */
+/* Same arithmetic as orc_dp_tables (bit-identical scores).                   */
+/* ======================================================================== */
+struct resident_prof
+{
+    unsigned M;
+    ofloat *t8; /* [8][M] */
+    ofloat *em; /* [1364][M] */
+    ofloat const *ei, *en;
+};
+
+static ofloat null_score_tables(ofloat const *emis_null, ofloat RR, unsigned char const *seq, unsigned L)
+{
+    ofloat PR[6], Rr = NEG_INF;
+    unsigned w = 0;
+    PR[0] = 0;
+    for (unsigned j = 1; j <= L; ++j)
+    {
+        w = ((w << 2) | seq[j - 1]) & 1023u;
+        unsigned maxl = j < 5 ? j : 5;
+        Rr = NEG_INF;
+        for (unsigned l = 1; l <= maxl; ++l)
+            Rr = omax(Rr, PR[(j - l) % 6] + emis_null[code_off[l] + (w & ((1u << (2 * l)) - 1))]);
+        PR[j % 6] = Rr + RR;
+    }
+    return Rr;
+}
+
+/* alt model only, caller-provided work area of 15*M floats */
+static ofloat alt_score_tables(struct resident_prof const *rp, ofloat const *xt, unsigned char const *seq,
+                               unsigned L, ofloat *work)
+{
+    unsigned const M = rp->M;
+    ofloat const *ENT = rp->t8, *MM = rp->t8 + M, *IM = rp->t8 + 2 * (size_t)M, *DM = rp->t8 + 3 * (size_t)M,
+                 *MD = rp->t8 + 4 * (size_t)M, *DD = rp->t8 + 5 * (size_t)M, *MI = rp->t8 + 6 * (size_t)M,
+                 *II = rp->t8 + 7 * (size_t)M;
+    ofloat const SB = xt[1], SN = xt[2], NN = xt[3], NB = xt[4], ET = xt[5], EC = xt[6], CC = xt[7],
+                 CT = xt[8], EB = xt[9], EJ = xt[10], JJ = xt[11], JB = xt[12];
+    ofloat *PM = work, *QI = work + 6 * (size_t)M, *Mr = work + 12 * (size_t)M, *Ir = work + 13 * (size_t)M,
+           *Dr = work + 14 * (size_t)M;
+    ofloat PN[6], PJ[6], PC[6];
+    {
+        ofloat B = 0 + SB;
+        for (unsigned k = 0; k < M; ++k)
+        {
+            PM[k] = B + ENT[k];
+            QI[k] = NEG_INF;
+        }
+        PN[0] = 0 + SN;
+        PJ[0] = PC[0] = NEG_INF;
+    }
+    ofloat E = NEG_INF, Cc = NEG_INF;
+    unsigned w = 0;
+    for (unsigned j = 1; j <= L; ++j)
+    {
+        w = ((w << 2) | seq[j - 1]) & 1023u;
+        unsigned maxl = j < 5 ? j : 5;
+        ofloat N = NEG_INF, J = NEG_INF;
+        Cc = NEG_INF;
+        for (unsigned k = 0; k < M; ++k)
+            Mr[k] = Ir[k] = NEG_INF;
+        for (unsigned l = 1; l <= maxl; ++l)
+        {
+            unsigned code = code_off[l] + (w & ((1u << (2 * l)) - 1));
+            unsigned r = (j - l) % 6;
+            ofloat eN = rp->en[code], eI = rp->ei[code];
+            ofloat const *restrict eM = rp->em + (size_t)code * M;
+            N = omax(N, PN[r] + eN);
+            J = omax(J, PJ[r] + eN);
+            Cc = omax(Cc, PC[r] + eN);
+            ofloat const *restrict pm = PM + (size_t)r * M, *restrict qi = QI + (size_t)r * M;
+            for (unsigned k = 0; k < M; ++k)
+            {
+                Mr[k] = omax(Mr[k], pm[k] + eM[k]);
+                Ir[k] = omax(Ir[k], qi[k] + eI);
+            }
+        }
+        Dr[0] = NEG_INF;
+        for (unsigned k = 1; k < M; ++k)
+            Dr[k] = omax(Mr[k - 1] + MD[k], Dr[k - 1] + DD[k]);
+        E = Mr[0];
+        for (unsigned k = 1; k < M; ++k)
+            E = omax(E, omax(Mr[k], Dr[k]));
+        ofloat B = omax(omax(N + NB, E + EB), J + JB);
+        unsigned r = j % 6;
+        ofloat *restrict pm = PM + (size_t)r * M, *restrict qi = QI + (size_t)r * M;
+        pm[0] = B + ENT[0];
+        for (unsigned k = 1; k < M; ++k)
+            pm[k] = omax(omax(B + ENT[k], Mr[k - 1] + MM[k]), omax(Ir[k - 1] + IM[k], Dr[k - 1] + DM[k]));
+        for (unsigned k = 0; k < M; ++k)
+            qi[k] = omax(Mr[k] + MI[k], Ir[k] + II[k]);
+        PN[r] = N + NN;
+        PJ[r] = omax(E + EJ, J + JJ);
+        PC[r] = omax(E + EC, Cc + CC);
+    }
+    return omax(E + ET, Cc + CT);
+}
+
+long orc_scan_resident(struct orc_profile *const *profiles, unsigned nprofiles,
+                       unsigned char const *seqs, uint32_t const *seq_off, unsigned nseqs,
+                       int multi_hits, int hmmer3_compat, double lrt_thr, int nthreads,
+                       ofloat *out_null, ofloat *out_alt, double *prepare_seconds, double *dp_seconds)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    for (unsigned q = 0; q < nseqs; ++q)
+        if (seq_off[q + 1] <= seq_off[q]) return -1;
+    double t0 = omp_get_wtime();
+    struct resident_prof *rp = calloc(nprofiles, sizeof *rp);
+    ofloat *xts = malloc(sizeof(ofloat) * 13 * (size_t)nseqs);
+    if (!rp || !xts)
+    {
+        free(rp), free(xts);
+        return -1;
+    }
+    unsigned maxM = 0;
+    /* once per DB: the tables every pair of this profile uses */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(max : maxM)
+    for (unsigned pi = 0; pi < nprofiles; ++pi)
+    {
+        struct orc_profile const *p = profiles[pi];
+        unsigned M = p->M;
+        rp[pi].M = M;
+        rp[pi].t8 = malloc(sizeof(ofloat) * 8 * (size_t)M);
+        rp[pi].em = malloc(sizeof(ofloat) * ORC_NCODES * (size_t)M);
+        rp[pi].ei = p->tbl_insert;
+        rp[pi].en = p->tbl_null;
+        orc_profile_export(p, rp[pi].t8, rp[pi].em, NULL, NULL, NULL);
+        if (M > maxM) maxM = M;
+    }
+    /* once per sequence: the 13 length-dependent transitions (protein_profile_setup) */
+    for (unsigned q = 0; q < nseqs; ++q)
+        orc_xtrans(seq_off[q + 1] - seq_off[q], multi_hits, hmmer3_compat, xts + 13 * (size_t)q);
+    double t1 = omp_get_wtime();
+    unsigned nparts = (unsigned)nthreads < nprofiles ? (unsigned)nthreads : nprofiles;
+    unsigned psize = ceildiv(nprofiles, nparts);
+    long hits = 0;
+#pragma omp parallel num_threads(nthreads) reduction(+ : hits)
+    {
+        ofloat *work = malloc(sizeof(ofloat) * 15 * (size_t)maxM);
+        ofloat *nullq = malloc(sizeof(ofloat) * (size_t)nseqs);
+#pragma omp for schedule(static, 1)
+        for (unsigned part = 0; part < nparts; ++part)
+        {
+            unsigned lo = part * psize;
+            unsigned hi = lo + psize < nprofiles ? lo + psize : nprofiles;
+            ofloat const *null_of = NULL; /* table the cached null scores were computed with */
+            for (unsigned pi = lo; pi < hi; ++pi)
+            {
+                /* null score: once per sequence for every run of profiles sharing one null table */
+                if (!null_of || memcmp(null_of, rp[pi].en, sizeof(ofloat) * ORC_NCODES))
+                {
+                    for (unsigned q = 0; q < nseqs; ++q)
+                        nullq[q] = null_score_tables(rp[pi].en, xts[13 * (size_t)q + 0], seqs + seq_off[q],
+                                                     seq_off[q + 1] - seq_off[q]);
+                    null_of = rp[pi].en;
+                }
+                for (unsigned q = 0; q < nseqs; ++q)
+                {
+                    ofloat nl = nullq[q];
+                    ofloat al = alt_score_tables(&rp[pi], xts + 13 * (size_t)q, seqs + seq_off[q],
+                                                 seq_off[q + 1] - seq_off[q], work);
+                    if (out_null) out_null[(size_t)q * nprofiles + pi] = nl;
+                    if (out_alt) out_alt[(size_t)q * nprofiles + pi] = al;
+                    ofloat lrt = orc_lrt(nl, al);
+                    if (isfinite((double)lrt) && !(lrt < (ofloat)lrt_thr)) hits++;
+                }
+            }
+        }
+        free(work), free(nullq);
+    }
+    double t2 = omp_get_wtime();
+    if (prepare_seconds) *prepare_seconds = t1 - t0;
+    if (dp_seconds) *dp_seconds = t2 - t1;
+    for (unsigned pi = 0; pi < nprofiles; ++pi)
+        free(rp[pi].t8), free(rp[pi].em);
+    free(rp), free(xts);
     return hits;
 }

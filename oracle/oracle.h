@@ -201,6 +201,20 @@ long orc_scan(struct orc_profile *const *profiles, unsigned nprofiles,
               unsigned nseqs, int multi_hits, int hmmer3_compat, double lrt_thr,
               int nthreads, int mode, ofloat *out_null, ofloat *out_alt);
 
+/* The 13 special transitions protein_profile_setup writes (protein_profile.c:155-216), in the
+ * order RR, SB, SN, NN, NB, ET, EC, CC, CT, EB, EJ, JJ, JB. ORC_EINVAL for seq_size == 0. */
+int orc_xtrans(unsigned seq_size, int multi_hits, int hmmer3_compat, ofloat xt[13]);
+
+/* Optimised CPU variant: DB resident -- tables exported once per profile --,
+ * null score once per (sequence, distinct null table), no allocation in the pair loop, every
+ * partition's thread runs its profiles over all sequences (no barrier per sequence).  Scores are
+ * bit-identical to orc_dp_tables / orc_scan mode 1.  prepare_seconds = the per-DB table export,
+ * dp_seconds = the pair loop (what a resident engine pays per batch). Returns hits or -1. */
+long orc_scan_resident(struct orc_profile *const *profiles, unsigned nprofiles,
+                       unsigned char const *seqs, uint32_t const *seq_off, unsigned nseqs,
+                       int multi_hits, int hmmer3_compat, double lrt_thr, int nthreads,
+                       ofloat *out_null, ofloat *out_alt, double *prepare_seconds, double *dp_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,3 +52,23 @@ def oracle64():
 @pytest.fixture(scope="session")
 def dcp():
     return load_product()
+
+
+@pytest.fixture(scope="session")
+def bench_mod():
+    """bench.py as a module: the workload generators (core sizes, queries) of BASELINE.json's configs."""
+    import bench
+    return bench
+
+
+@pytest.fixture(scope="session")
+def c3_profiles(dcp, bench_mod):
+    """The C3 / C4 database: 20 000 sampled profiles (host objects, built once per session)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    sizes = bench_mod.core_sizes_for("c3", 20000)
+    cfg = dcp.ProteinCfg(2, 0.01)  # ENTRY_DIST_OCCUPANCY
+    with ThreadPoolExecutor(16) as ex:
+        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
+                               range(len(sizes))))
+    return sizes, profiles

@@ -110,12 +110,14 @@ class Profile:
 
 
 class Oracle:
-    def __init__(self, bits=32):
-        build_oracle()
+    def __init__(self, bits=32, lib_path=None):
+        """lib_path: another build of oracle.c (bench.py's -O3 -march=native CPU-baseline build)."""
+        if lib_path is None:
+            build_oracle()
         self.bits = bits
         self.fl = C.c_double if bits == 64 else C.c_float
         self.np = np.float64 if bits == 64 else np.float32
-        lib = C.CDLL(os.path.join(ORACLE_DIR, f"liboracle_f{bits}.so"))
+        lib = C.CDLL(lib_path or os.path.join(ORACLE_DIR, f"liboracle_f{bits}.so"))
         fl = self.fl
         lib.orc_profile_sample.restype = C.c_void_p
         lib.orc_profile_sample.argtypes = [C.c_uint, C.c_uint, C.c_int, fl]
@@ -150,6 +152,11 @@ class Oracle:
         lib.orc_scan.restype = C.c_long
         lib.orc_scan.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_uint, C.c_int,
                                  C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orc_scan_resident.restype = C.c_long
+        lib.orc_scan_resident.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_void_p, C.c_uint, C.c_int,
+                                          C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.orc_xtrans.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_void_p]
         lib.orc_rnd_seed.argtypes = [C.c_void_p, C.c_uint64]
         lib.orc_rnd_dbl.restype = C.c_double
         lib.orc_rnd_dbl.argtypes = [C.c_void_p]
@@ -216,3 +223,28 @@ class Oracle:
                                  int(hmmer3_compat), float(lrt_thr), nthreads, mode,
                                  on.ctypes.data, oa.ctypes.data)
         return hits, on, oa
+
+    def scan_resident(self, profiles, seqs, multi_hits=True, hmmer3_compat=False, lrt_thr=10.0,
+                      nthreads=1, want_scores=True):
+        """Optimised CPU variant (DB resident, null once per sequence).
+        returns (hits, null, alt, prepare_seconds, dp_seconds)."""
+        n = len(profiles)
+        arr = (C.c_void_p * n)(*[p.h for p in profiles])
+        off = np.zeros(len(seqs) + 1, np.uint32)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        cat = b"".join(seqs)
+        on = np.zeros((len(seqs), n), self.np) if want_scores else None
+        oa = np.zeros((len(seqs), n), self.np) if want_scores else None
+        tp, td = C.c_double(0), C.c_double(0)
+        hits = self.lib.orc_scan_resident(arr, n, cat, off.ctypes.data, len(seqs), int(multi_hits),
+                                          int(hmmer3_compat), float(lrt_thr), nthreads,
+                                          on.ctypes.data if want_scores else None,
+                                          oa.ctypes.data if want_scores else None, C.byref(tp), C.byref(td))
+        if hits < 0:
+            raise ValueError("orc_scan_resident: bad input")
+        return hits, on, oa, tp.value, td.value
+
+    def xtrans(self, L, multi_hits=True, hmmer3_compat=False):
+        out = np.zeros(13, self.np)
+        rc = self.lib.orc_xtrans(L, int(multi_hits), int(hmmer3_compat), out.ctypes.data)
+        return rc, out

@@ -42,3 +42,17 @@ def test_scanner_fails_loudly_without_gpu(dcp):
         pytest.skip("a HIP device is present")
     with pytest.raises(dcp.DcpError):
         dcp.Scanner(0)
+
+
+def test_no_result_changing_environment_hooks():
+    """Nothing in the shipped sources reads the environment: kernel choice goes
+    through dcp_scan_params.kernel, the redo-list cap through a test-only setter, and the timing
+    diagnostics of the query-lane kernel exist only as a compile-time -DDCP_QLANE_DIAG build."""
+    bad = []
+    for sub in ("csrc", "host"):
+        d = os.path.join(ROOT, "deciphon-old_amd", sub)
+        for f in os.listdir(d):
+            if f.endswith((".cpp", ".hip", ".h", ".c")):
+                if re.search(r"\bgetenv\b|\benviron\b", open(os.path.join(d, f), errors="ignore").read()):
+                    bad.append(f)
+    assert not bad, bad

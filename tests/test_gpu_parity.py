@@ -246,9 +246,9 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
     assert a_multi > a_uni
 
 
-def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner, monkeypatch):
+def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner):
     """More feedback pairs than a redo list holds: the scan is repeated by the row-sweep kernel
-    and stays bit-exact (DCP_REDO_CAP shrinks the lists to one pair per size class)."""
+    and stays bit-exact (the test-only setter shrinks the lists to one pair per size class)."""
     rng = np.random.default_rng(33)
     M = 60
     prm = pfam_like_params(rng, M)
@@ -265,12 +265,15 @@ def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner, monk
     assert scanner.last_scan_redo_pairs >= 3
     gn, ga = scanner.scores()
     assert same_bits(gn, on) and same_bits(ga, oa)
-    monkeypatch.setenv("DCP_REDO_CAP", "1")
-    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
-    gn, ga = scanner.scores()
-    assert same_bits(gn, on) and same_bits(ga, oa)
-    got = sorted((int(h["seq_idx"]), int(h["profile_idx"])) for h in scanner.hits())
-    assert got[:3] == [(0, 0), (1, 0), (2, 0)]
+    scanner.test_set_redo_cap(1)
+    try:
+        scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
+        gn, ga = scanner.scores()
+        assert same_bits(gn, on) and same_bits(ga, oa)
+        got = sorted((int(h["seq_idx"]), int(h["profile_idx"])) for h in scanner.hits())
+        assert got[:3] == [(0, 0), (1, 0), (2, 0)]
+    finally:
+        scanner.test_set_redo_cap(0)
 
 
 @pytest.mark.parametrize("M", [300, 600, 1300, 2600])
@@ -569,27 +572,17 @@ def test_long_sequences(dcp, oracle32, scanner, kern):
     assert np.isfinite(ga).all()
 
 
-def test_full_size_c3_step_both_kernels_agree(dcp, oracle32):
+def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_mod):
     """BASELINE.json's headline size: one bench step = 20 000 profiles (sum M = 3.57e6) x 1 000 queries of
     1 000 nt = 2e7 pairs, 3.6e12 cells.  Too big for the oracle, so a size-independent property: the two
     independent device implementations (row sweep, query lane + redo) agree bit for bit on every one of the
     2e7 null and alt scores and on the hit list, and a few sampled pairs are checked against the oracle."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    from concurrent.futures import ThreadPoolExecutor
-
-    sizes = bench.core_sizes_for("c3", 20000)
-    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
-    with ThreadPoolExecutor(16) as ex:
-        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
-                               range(len(sizes))))
+    bench = bench_mod
+    sizes, profiles = c3_profiles
     queries = bench.make_queries(0, 1000, 1000)
     sc = dcp.Scanner(0)
     try:
         sc.upload_db(profiles)
-        del profiles
         sc.upload_seqs_flat(queries.reshape(-1), (np.arange(1001, dtype=np.uint64) * 1000).astype(np.uint32))
         out = {}
         for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
