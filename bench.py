@@ -276,14 +276,49 @@ def main():
     sc.set_hit_buffer(hit_words.data_ptr(), cap, hit_count.data_ptr())
 
     hits_seen = []
-    gather_kind = "torch.distributed all_gather"
+    # N > 1: the hit gather of the C host (dcp_dist_*: librccl loaded by the library, counts all-gather +
+    # grouped send/recv), bootstrapped with torch.distributed (rank 0's ncclUniqueId is broadcast).  If the
+    # C communicator cannot be created on every rank, all ranks fall back to the torch.distributed
+    # transport (same C bookkeeping) and the JSON line says so.
+    gather_kind = "torch.distributed all_gather + dcp_dist_merge_hits"
+    cdist = None
+    if (world > 1 or force_dist) and args.hit_gather == "c":
+        idt = torch.zeros(ddist.ID_BYTES, dtype=torch.uint8, device="cuda")
+        why = ""
+        if rank == 0:
+            try:
+                idt.copy_(torch.frombuffer(bytearray(ddist.CDist.unique_id()), dtype=torch.uint8))
+            except Exception as ex:  # librccl not loadable: every rank sees the all-zero id
+                why = str(ex)
+        dist.broadcast(idt, 0)
+        id_bytes = bytes(idt.cpu().numpy().tobytes())
+        if any(id_bytes):
+            try:
+                cdist = ddist.CDist.create(id_bytes, rank, world, local_rank)
+            except Exception as ex:
+                why = str(ex)
+        ok = torch.tensor([1 if cdist else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            gather_kind = "C host dcp_dist_gather_hits: librccl all-gather of counts + grouped ncclSend/ncclRecv"
+        else:
+            if cdist:
+                cdist.close()
+            cdist = None
+            gather_kind += f" (C RCCL communicator unavailable{': ' + why if why else ''})"
     kernel_id = {"auto": dcp.KERNEL_AUTO, "rowsweep": dcp.KERNEL_ROWSWEEP, "qlane": dcp.KERNEL_QLANE}[args.kernel]
 
     def step(i):
         sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep),
                 kernel=kernel_id)
         sc.sync()
-        if world > 1 or force_dist:
+        if cdist:
+            h, total = cdist.gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
+            if i < args.warmup:  # untimed cross-check of the C gather against a torch collective
+                tot = hit_count.to(torch.int64).clone()
+                dist.all_reduce(tot)
+                assert int(tot.item()) == total == len(h), (int(tot.item()), total, len(h))
+        elif world > 1 or force_dist:
             h = ddist.gather_hits(hit_words, hit_count, b)
         else:
             h = None
@@ -455,6 +490,8 @@ def main():
                                    "hits_total": len(found)}
         print(json.dumps(out))
     sc.close()
+    if cdist:
+        cdist.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -46,6 +46,11 @@ NUM_THREADS = 64
 # every symbol include/dcp_gpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dcp_profile_new", "dcp_profile_sample", "dcp_profile_del", "dcp_profile_core_size",
+    "dcp_profile_from_parts", "dcp_profile_entry_dist", "dcp_profile_epsilon", "dcp_rnd_seed", "dcp_rnd_next",
+    "dcp_dist_unique_id", "dcp_dist_init", "dcp_dist_init_from_file", "dcp_dist_free", "dcp_dist_rank",
+    "dcp_dist_nranks", "dcp_dist_last_error", "dcp_dist_shard", "dcp_dist_gather_hits", "dcp_dist_free_hits",
+    "dcp_dist_merge_hits",
+    "dcp_lprob_normalize", "dcp_h3reader_open_fp", "dcp_h3reader_next_params", "dcp_gpu_seqs_set_xtrans",
     "dcp_profile_accession", "dcp_profile_trans8", "dcp_profile_null_dist",
     "dcp_profile_insert_dist", "dcp_profile_match_dist", "dcp_frame_table_host", "dcp_xtrans",
     "dcp_lrt", "dcp_partition_by_count", "dcp_partition_by_cells", "dcp_gpu_device_count",
@@ -132,6 +137,7 @@ def _load():
         "dcp_gpu_seqs_upload": (I, [P, P, P, U]),
         "dcp_gpu_seqs_upload_text": (I, [P, C.c_char_p, P, U]),
         "dcp_gpu_nseqs": (U, [P]),
+        "dcp_gpu_seqs_set_xtrans": (I, [P, P, U]),
         "dcp_gpu_scan": (I, [P, C.POINTER(ScanParams)]),
         "dcp_gpu_sync": (I, [P]),
         "dcp_gpu_test_set_redo_cap": (I, [P, U]),
@@ -505,6 +511,12 @@ class Scanner:
         off = np.ascontiguousarray(off, np.uint32)
         self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
         self._seq_lens = np.diff(off.astype(np.int64))
+
+    def set_xtrans(self, xt):
+        """Explicit special transitions [nseqs, 13] for the resident sequences (dcp_gpu_seqs_set_xtrans):
+        what imm_dp_viterbi uses for a profile whose transitions were not set from the sequence length."""
+        xt = np.ascontiguousarray(xt, np.float32).reshape(-1, NXTRANS)
+        self._check(lib.dcp_gpu_seqs_set_xtrans(self._c, xt.ctypes.data, len(xt)))
 
     def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
              sync=True, q_range=None, kernel=KERNEL_AUTO):

@@ -117,6 +117,7 @@ struct dcp_gpu_ctx
     DevBuf<uint32_t> d_seq_words, d_seq_woff, d_seq_len;
     DevBuf<float> d_xtrans;
     int xt_multi = -1, xt_h3 = -1;
+    bool xt_explicit = false; // dcp_gpu_seqs_set_xtrans: the caller's transitions, not the length-derived ones
 
     // results
     DevBuf<float> d_null, d_alt;
@@ -613,6 +614,7 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
     c->nseqs = nseqs;
     c->total_len = total;
     c->xt_multi = c->xt_h3 = -1;
+    c->xt_explicit = false;
     // the length order and the transposed word planes belong to the batch that was resident
     c->qorder_q0 = c->qorder_q1 = ~0u;
     return DCP_OK;
@@ -635,6 +637,7 @@ static int finish_scan(dcp_gpu_ctx *c);
 // protein_profile_setup once per sequence (length) instead of once per pair
 static int ensure_xtrans(dcp_gpu_ctx *c, int multi_hits, int hmmer3_compat)
 {
+    if (c->xt_explicit) return DCP_OK;
     if (c->xt_multi == !!multi_hits && c->xt_h3 == !!hmmer3_compat) return DCP_OK;
     std::vector<float> xt((size_t)c->nseqs * DCP_XSTRIDE, 0.0f);
     std::map<uint32_t, std::vector<float>> by_len;
@@ -655,6 +658,25 @@ static int ensure_xtrans(dcp_gpu_ctx *c, int multi_hits, int hmmer3_compat)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->xt_multi = !!multi_hits;
     c->xt_h3 = !!hmmer3_compat;
+    return DCP_OK;
+}
+
+int dcp_gpu_seqs_set_xtrans(dcp_gpu_ctx *c, float const *xt, unsigned nseqs)
+{
+    if (!c) return DCP_EINVAL;
+    if (!xt || nseqs == 0 || nseqs != c->nseqs) return c->fail(DCP_EINVAL, "xtrans must cover the resident sequences");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> buf((size_t)nseqs * DCP_XSTRIDE, 0.0f);
+    for (unsigned q = 0; q < nseqs; ++q)
+        for (int i = 0; i < DCP_NXTRANS; ++i)
+        {
+            float const v = xt[(size_t)q * DCP_NXTRANS + i];
+            if (v != v) return c->fail(DCP_EINVAL, "NaN special transition");
+            buf[(size_t)q * DCP_XSTRIDE + i] = v;
+        }
+    HIP_TRY(c, hipMemcpy(c->d_xtrans.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->xt_explicit = true;
+    c->xt_multi = c->xt_h3 = -1;
     return DCP_OK;
 }
 
@@ -853,7 +875,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.ntasks = (unsigned)ntasks;
         // redo lists: pairs whose multi-hit feedback beat B0 go to the row-sweep kernel, which
         // runs right behind the query-lane kernel on this stream (uni-hit scans have no feedback)
-        bool const redo = prm->multi_hits != 0;
+        bool const redo = prm->multi_hits != 0 || c->xt_explicit; // explicit transitions may carry E->B feedback
         unsigned redo_grid[kNumClasses] = {0};
         if (redo)
         {

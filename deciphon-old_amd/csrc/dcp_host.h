@@ -40,12 +40,4 @@ enum
     DCP_XSTRIDE = 16, // floats per sequence in the device xtrans array
 };
 
-#ifdef __cplusplus
-extern "C" {
-#endif
-float dcp_profile_epsilon(dcp_profile const *p);
-#ifdef __cplusplus
-}
-#endif
-
 #endif

@@ -303,6 +303,72 @@ dcp_profile *dcp_profile_sample(char const *accession, unsigned seed,
                            match.data(), trans.data(), nullptr, rc);
 }
 
+dcp_profile *dcp_profile_from_parts(char const *accession, unsigned core_size, int entry_dist, float epsilon,
+                                    char const *consensus, float const *trans8, float const *null_dist,
+                                    float const *insert_dist, float const *match_dist, int *rc)
+{
+    auto fail = [&](int code) -> dcp_profile * {
+        if (rc) *rc = code;
+        return nullptr;
+    };
+    if (core_size == 0 || core_size > DCP_CORE_SIZE_MAX) return fail(DCP_EINVAL);
+    if (!trans8 || !null_dist || !insert_dist || !match_dist) return fail(DCP_EINVAL);
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail(DCP_EINVAL);
+    dcp_profile *p = new (std::nothrow) dcp_profile();
+    if (!p) return fail(DCP_ENOMEM);
+    unsigned const M = core_size;
+    std::memset(p->accession, 0, sizeof p->accession);
+    if (accession) std::strncpy(p->accession, accession, sizeof p->accession - 1);
+    p->core_size = M;
+    p->entry_dist = entry_dist;
+    p->epsilon = epsilon;
+    p->consensus.assign(M + 1, '\0');
+    bool ended = !consensus;
+    for (unsigned i = 0; i < M; ++i)
+    {
+        if (!ended && consensus[i] == '\0') ended = true;
+        p->consensus[i] = ended ? '-' : consensus[i];
+    }
+    p->trans8.assign(trans8, trans8 + (size_t)8 * M);
+    p->match_dist.assign(match_dist, match_dist + (size_t)M * DCP_NDIST);
+    std::memcpy(p->null_dist, null_dist, sizeof p->null_dist);
+    std::memcpy(p->insert_dist, insert_dist, sizeof p->insert_dist);
+    // a NaN anywhere would poison every max: reject it here rather than on the device
+    for (float v : p->trans8)
+        if (v != v) { delete p; return fail(DCP_EINVAL); }
+    for (float v : p->match_dist)
+        if (v != v) { delete p; return fail(DCP_EINVAL); }
+    for (int i = 0; i < DCP_NDIST; ++i)
+        if (p->null_dist[i] != p->null_dist[i] || p->insert_dist[i] != p->insert_dist[i]) { delete p; return fail(DCP_EINVAL); }
+    if (rc) *rc = DCP_OK;
+    return p;
+}
+
+void dcp_rnd_seed(uint64_t state[4], uint64_t seed)
+{
+    Rnd r(seed);
+    std::memcpy(state, r.s, sizeof r.s);
+}
+
+double dcp_rnd_next(uint64_t state[4])
+{
+    Rnd r(0);
+    std::memcpy(r.s, state, sizeof r.s);
+    double const v = r.next();
+    std::memcpy(state, r.s, sizeof r.s);
+    return v;
+}
+
+void dcp_lprob_normalize(unsigned n, float *lprobs)
+{
+    std::vector<double> lp(lprobs, lprobs + n);
+    double const z = logsumexp(lp.data(), (int)n);
+    for (unsigned i = 0; i < n; ++i)
+        lprobs[i] = (float)(lp[i] - z);
+}
+
+int dcp_profile_entry_dist(dcp_profile const *p) { return p->entry_dist; }
+
 void dcp_profile_del(dcp_profile *p) { delete p; }
 unsigned dcp_profile_core_size(dcp_profile const *p) { return p->core_size; }
 char const *dcp_profile_accession(dcp_profile const *p) { return p->accession; }
@@ -660,16 +726,23 @@ long dcp_prod_format_row(char *buf, size_t cap, int64_t scan_id, int64_t seq_id,
 // ---------------------------------------------------------------------------
 // HMMER3 ASCII reader
 // ---------------------------------------------------------------------------
-#include <fstream>
 #include <sstream>
 
 struct dcp_h3reader
 {
-    std::ifstream in;
+    FILE *fp = nullptr;
+    bool owns_fp = false;
     int entry_dist;
     float epsilon;
     std::string err;
     unsigned line_no = 0;
+    // parameters of the profile the last next() parsed (dcp_h3reader_next_params)
+    std::vector<float> trans, match;
+    std::string cons, name, acc;
+    ~dcp_h3reader()
+    {
+        if (fp && owns_fp) std::fclose(fp);
+    }
 };
 
 namespace
@@ -713,42 +786,58 @@ void dcp_swissprot_null_lprobs(float out[DCP_AMINO_SIZE])
         out[i] = (float)std::log(freq[i]);
 }
 
+dcp_h3reader *dcp_h3reader_open_fp(FILE *fp, int entry_dist, float epsilon)
+{
+    if (!fp) return nullptr;
+    dcp_h3reader *r = new (std::nothrow) dcp_h3reader();
+    if (!r) return nullptr;
+    r->fp = fp;
+    r->entry_dist = entry_dist;
+    r->epsilon = epsilon;
+    return r;
+}
+
 dcp_h3reader *dcp_h3reader_open(char const *path, int entry_dist, float epsilon)
 {
     if (!path) return nullptr;
-    dcp_h3reader *r = new (std::nothrow) dcp_h3reader();
-    if (!r) return nullptr;
-    r->in.open(path);
-    if (!r->in)
-    {
-        delete r;
-        return nullptr;
-    }
-    r->entry_dist = entry_dist;
-    r->epsilon = epsilon;
+    FILE *fp = std::fopen(path, "r");
+    if (!fp) return nullptr;
+    dcp_h3reader *r = dcp_h3reader_open_fp(fp, entry_dist, epsilon);
+    if (!r) std::fclose(fp);
+    else r->owns_fp = true;
     return r;
 }
 
 char const *dcp_h3reader_error(dcp_h3reader const *r) { return r ? r->err.c_str() : "no reader"; }
 void dcp_h3reader_close(dcp_h3reader *r) { delete r; }
 
-int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
+int dcp_h3reader_next_params(dcp_h3reader *r, struct dcp_h3params *out)
 {
     if (!r || !out) return DCP_EINVAL;
-    *out = nullptr;
+    std::memset(out, 0, sizeof *out);
     auto parse_error = [&](std::string const &what) {
         r->err = "line " + std::to_string(r->line_no) + ": " + what;
         return (int)DCP_EPARSE;
     };
     std::string line;
     auto next_line = [&]() -> bool {
-        while (std::getline(r->in, line))
+        char buf[4096];
+        for (;;)
         {
+            line.clear();
+            bool got = false;
+            while (std::fgets(buf, sizeof buf, r->fp)) // a line may be longer than the buffer
+            {
+                got = true;
+                line += buf;
+                if (!line.empty() && line.back() == '\n') break;
+            }
+            if (!got) return false;
             ++r->line_no;
-            if (!line.empty() && line.back() == '\r') line.pop_back();
+            while (!line.empty() && (line.back() == '\n' || line.back() == '\r'))
+                line.pop_back();
             if (line.find_first_not_of(" \t") != std::string::npos) return true;
         }
-        return false;
     };
 
     // ---- header -----------------------------------------------------------
@@ -793,8 +882,11 @@ int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
         return DCP_EINVAL; // protein_model_setup: protein_model.c:157-160
     }
 
-    std::vector<float> trans((size_t)7 * (leng + 1)), match((size_t)20 * leng);
-    std::string cons(leng, '-');
+    std::vector<float> &trans = r->trans, &match = r->match;
+    std::string &cons = r->cons;
+    trans.assign((size_t)7 * (leng + 1), 0.0f);
+    match.assign((size_t)20 * leng, 0.0f);
+    cons.assign(leng, '-');
     auto read_trans = [&](unsigned i) -> bool {
         std::vector<std::string> f = h3_split(line);
         if (f.size() != 7) return false;
@@ -826,12 +918,29 @@ int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
     }
     if (!next_line() || h3_split(line)[0] != "//") return parse_error("expected the // terminator");
 
+    r->name = name;
+    r->acc = acc;
+    out->core_size = leng;
+    out->match_lprobs = match.data();
+    out->trans = trans.data();
+    out->consensus = cons.c_str();
+    out->name = r->name.c_str();
+    out->acc = r->acc.c_str();
+    return DCP_OK;
+}
+
+int dcp_h3reader_next(dcp_h3reader *r, dcp_profile **out)
+{
+    if (!r || !out) return DCP_EINVAL;
+    *out = nullptr;
+    struct dcp_h3params prm;
+    int rc = dcp_h3reader_next_params(r, &prm);
+    if (rc) return rc;
     float null_lp[20];
     dcp_swissprot_null_lprobs(null_lp);
-    int rc = DCP_OK;
-    std::string const &label = acc.empty() ? name : acc;
-    *out = dcp_profile_new(label.c_str(), leng, r->entry_dist, r->epsilon, null_lp, match.data(), trans.data(),
-                           cons.c_str(), &rc);
+    char const *label = prm.acc[0] ? prm.acc : prm.name; // hmm.c:113-117
+    *out = dcp_profile_new(label, prm.core_size, r->entry_dist, r->epsilon, null_lp, prm.match_lprobs, prm.trans,
+                           prm.consensus, &rc);
     if (!*out) r->err = "profile rejected";
     return rc;
 }

@@ -1,0 +1,549 @@
+/*
+ * dcp_server.c -- C11 host layer, part 3: products, scan threads and the scan loop
+ * (include/deciphon_host.h section "server").
+ *
+ * Reference files followed (behaviour, not code): src/server/prod.c, src/server/protein_match.c:21-56,
+ * src/server/scan_thread.c:9-135, src/server/scan.c:45-74,215-269.  One scan thread = one database
+ * partition = one device context; the partition's profiles are unpacked and uploaded ONCE and stay
+ * resident, where the reference re-reads and re-unpacks them for every sequence.
+ */
+#include "deciphon_host.h"
+#include "host_internal.h"
+
+#include <inttypes.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#define fail dcp_host_fail
+
+/* ============================== products (src/server/prod.c) ================================== */
+struct tmp_file
+{
+    FILE *fp;
+    char path[64];
+};
+static unsigned num_threads;
+static struct tmp_file prod_file[NUM_THREADS];
+static struct tmp_file final_file;
+
+static enum rc tmp_open(struct tmp_file *t)
+{
+    snprintf(t->path, sizeof t->path, "%s/dcp_prod_XXXXXX", P_tmpdir);
+    int fd = mkstemp(t->path);
+    if (fd < 0) return fail(RC_EIO, "mkstemp");
+    t->fp = fdopen(fd, "wb+");
+    if (!t->fp)
+    {
+        close(fd);
+        unlink(t->path);
+        return fail(RC_EIO, "fdopen");
+    }
+    return RC_OK;
+}
+
+static void tmp_del(struct tmp_file *t)
+{
+    if (t->fp)
+    {
+        fclose(t->fp);
+        unlink(t->path);
+    }
+    t->fp = NULL;
+    t->path[0] = '\0';
+}
+
+enum rc prod_fopen(unsigned nthreads)
+{
+    assert(nthreads <= NUM_THREADS);
+    prod_fcleanup();
+    for (num_threads = 0; num_threads < nthreads; ++num_threads)
+        if (tmp_open(prod_file + num_threads))
+        {
+            prod_fcleanup();
+            return fail(RC_EFAIL, "begin prod submission");
+        }
+    return RC_OK;
+}
+
+void prod_setup_job(struct prod *prod, char const *abc_name, char const *prof_typeid, int64_t scan_id)
+{
+    snprintf(prod->abc_name, sizeof prod->abc_name, "%s", abc_name);
+    snprintf(prod->profile_typeid, sizeof prod->profile_typeid, "%s", prof_typeid);
+    snprintf(prod->version, sizeof prod->version, "%s", DECIPHON_VERSION);
+    prod->scan_id = scan_id;
+}
+
+void prod_setup_seq(struct prod *prod, int64_t seq_id) { prod->seq_id = seq_id; }
+
+void prod_fcleanup(void)
+{
+    for (unsigned i = 0; i < NUM_THREADS; ++i)
+        tmp_del(prod_file + i);
+    num_threads = 0;
+}
+
+char const *prod_header(void) { return dcp_prod_header(); }
+
+enum rc prod_fclose(void)
+{
+    enum rc rc = RC_OK;
+    tmp_del(&final_file);
+    if (tmp_open(&final_file))
+    {
+        rc = fail(RC_EIO, "fail to finish product");
+        goto cleanup;
+    }
+    fputs(prod_header(), final_file.fp);
+    for (unsigned i = 0; i < num_threads && !rc; ++i)
+    {
+        char buf[1 << 16];
+        size_t n;
+        if (fflush(prod_file[i].fp)) rc = fail(RC_EIO, "failed to flush");
+        rewind(prod_file[i].fp);
+        while (!rc && (n = fread(buf, 1, sizeof buf, prod_file[i].fp)) > 0)
+            if (fwrite(buf, 1, n, final_file.fp) != n) rc = fail(RC_EIO, "failed to copy products");
+    }
+    if (!rc && fflush(final_file.fp)) rc = fail(RC_EIO, "failed to flush");
+    if (rc) tmp_del(&final_file);
+    else rewind(final_file.fp);
+
+cleanup:
+    prod_fcleanup();
+    return rc;
+}
+
+FILE *prod_final_fp(void) { return final_file.fp; }
+char const *prod_final_path(void) { return final_file.path; }
+void prod_final_cleanup(void) { tmp_del(&final_file); }
+
+/* One products row: eight tab-separated fields, then the match column -- one "frag,state,codon,amino"
+ * item per path step, ';'-separated, each written by the caller's fwrite_match (prod.c:13-41,153-181). */
+enum rc prod_fwrite(struct prod const *prod, struct imm_seq const *seq, struct imm_path const *path,
+                    unsigned thread_num, prod_fwrite_match_func_t fwrite_match, struct match *match)
+{
+    if (thread_num >= NUM_THREADS) return fail(RC_EINVAL, "thread number out of range");
+    if (!prod_file[thread_num].fp)
+    {
+        /* thread_run driven without scan_run's prod_fopen (library-level use): open on demand */
+        if (tmp_open(prod_file + thread_num)) return fail(RC_EIO, "failed to write prod");
+        if (num_threads <= thread_num) num_threads = thread_num + 1;
+    }
+    FILE *fp = prod_file[thread_num].fp;
+    if (fprintf(fp, "%" PRId64 "\t%" PRId64 "\t%s\t%s\t%.17g\t%.17g\t%s\t%s\t", prod->scan_id, prod->seq_id,
+                prod->profile_name, prod->abc_name, prod->alt_loglik, prod->null_loglik, prod->profile_typeid,
+                prod->version) < 0)
+        return fail(RC_EIO, "failed to write prod");
+    unsigned start = 0;
+    unsigned const n = imm_path_nsteps(path);
+    for (unsigned idx = 0; idx < n; idx++)
+    {
+        match->step = imm_path_step(path, idx);
+        if (start + match->step->seqlen > seq->size) return fail(RC_EINVAL, "path does not fit the sequence");
+        struct imm_seq frag = imm_subseq(seq, start, match->step->seqlen);
+        match->frag = &frag;
+        if (idx > 0 && fputc(';', fp) == EOF) return fail(RC_EIO, "failed to write prod");
+        if (fwrite_match(fp, match)) return fail(RC_EIO, "write prod");
+        start += match->step->seqlen;
+    }
+    match->frag = NULL;
+    if (fputc('\n', fp) == EOF) return fail(RC_EIO, "failed to write prod");
+    return RC_OK;
+}
+
+/* src/server/protein_match.c:21-56 */
+enum rc protein_match_write_func(FILE *fp, void const *match)
+{
+    struct match const *m = match;
+    struct protein_profile const *prof = (struct protein_profile const *)m->profile;
+    struct imm_step const *step = m->step;
+    struct imm_seq const *f = m->frag;
+    struct imm_codon codon = imm_codon_any(prof->code->nuclt);
+    char state[IMM_STATE_NAME_SIZE] = {0};
+    m->profile->state_name(step->state_id, state);
+    char ccodon[4] = {0}, camino[2] = {0};
+    if (!protein_state_is_mute(step->state_id))
+    {
+        if (protein_profile_decode(prof, f, step->state_id, &codon)) return fail(RC_EIO, "failed to write match");
+        ccodon[0] = imm_codon_asym(&codon);
+        ccodon[1] = imm_codon_bsym(&codon);
+        ccodon[2] = imm_codon_csym(&codon);
+        camino[0] = imm_gc_decode(1, codon);
+    }
+    if (fprintf(fp, "%.*s,%s,%s,%s", (int)f->size, f->str, state, ccodon, camino) < 0)
+        return fail(RC_EIO, "failed to write match");
+    return RC_OK;
+}
+
+/* ============================== scan thread (src/server/scan_thread.c) ========================= */
+void thread_init(struct scan_thread *t, unsigned id, struct profile_reader *reader, bool multi_hits,
+                 bool hmmer3_compat, double lrt_threshold, prod_fwrite_match_func_t write_match_func)
+{
+    memset(t, 0, sizeof *t);
+    t->id = id;
+    t->reader = reader;
+    t->multi_hits = multi_hits;
+    t->hmmer3_compat = hmmer3_compat;
+    t->lrt_threshold = lrt_threshold;
+    t->write_match_func = write_match_func;
+    t->null.prod = imm_prod();
+    t->alt.prod = imm_prod();
+}
+
+void thread_setup_job(struct scan_thread *t, enum imm_abc_typeid abc_typeid, enum profile_typeid typeid,
+                      int64_t scan_id)
+{
+    prod_setup_job(&t->prod, imm_abc_typeid_name(abc_typeid), profile_typeid_name(typeid), scan_id);
+}
+
+void thread_setup_seq(struct scan_thread *t, struct imm_seq *seq, int64_t seq_id)
+{
+    t->seq = seq;
+    prod_setup_seq(&t->prod, seq_id);
+}
+
+void thread_cleanup(struct scan_thread *t)
+{
+    if (t->gpu) dcp_gpu_ctx_del(t->gpu);
+    for (unsigned i = 0; i < t->nimpls; ++i)
+        dcp_profile_del(t->impls[i]);
+    free(t->impls);
+    imm_prod_del(&t->null.prod);
+    imm_prod_del(&t->alt.prod);
+    imm_task_del(t->null.task);
+    imm_task_del(t->alt.task);
+    t->gpu = NULL;
+    t->impls = NULL;
+    t->nimpls = 0;
+    t->null.task = t->alt.task = NULL;
+    t->null.prod = t->alt.prod = imm_prod();
+    t->db_resident = false;
+}
+
+/* Unpack the partition once (the reference does this per sequence: scan_thread.c:96-99), keep the
+ * compact profiles on the host for decoding and upload them to the thread's device context. */
+static enum rc thread_prepare(struct scan_thread *t, int tid)
+{
+    struct profile_reader *reader = t->reader;
+    unsigned const n = reader->partition_size[t->id];
+    if (!t->gpu)
+    {
+        int ndev = dcp_gpu_device_count();
+        if (ndev <= 0) return fail(RC_EFAIL, "no HIP device: thread_run has no CPU implementation here");
+        t->gpu = dcp_gpu_ctx_new((tid < 0 ? 0 : tid) % ndev);
+        if (!t->gpu) return fail(RC_EFAIL, "failed to create the device context");
+    }
+    if (t->db_resident) return RC_OK;
+    t->impls = calloc(n ? n : 1, sizeof *t->impls);
+    if (!t->impls) return fail(RC_ENOMEM, "alloc");
+    enum rc rc = profile_reader_rewind(reader, t->id);
+    struct profile *prof = NULL;
+    while (!rc && (rc = profile_reader_next(reader, t->id, &prof)) == RC_OK)
+    {
+        if (t->nimpls == n)
+        {
+            rc = fail(RC_EPARSE, "partition %u holds more profiles than its size %u", t->id, n);
+            break;
+        }
+        /* the reader's profile object is reused by the next call: move its compact form out */
+        struct protein_profile *pp = (struct protein_profile *)prof;
+        t->impls[t->nimpls++] = pp->impl;
+        dcp_host_forget_profile(pp->impl);
+        pp->impl = NULL;
+    }
+    if (rc == RC_END) rc = t->nimpls == n ? RC_OK : fail(RC_EPARSE, "partition %u: %u of %u profiles", t->id, t->nimpls, n);
+    if (!rc && dcp_gpu_db_upload(t->gpu, t->impls, n, 0)) rc = fail(RC_EFAIL, "%s", dcp_gpu_last_error(t->gpu));
+    if (rc) return rc;
+    t->db_resident = true;
+    return RC_OK;
+}
+
+/* a borrowed view of resident profile i, complete enough for write_match_func callbacks */
+static enum rc profile_view(struct scan_thread *t, unsigned i, struct protein_profile *view)
+{
+    struct protein_profile const *tmpl = &t->reader->profiles[t->id].pro;
+    dcp_profile *impl = t->impls[i];
+    protein_profile_init(view, dcp_profile_accession(impl), tmpl->amino, tmpl->code, tmpl->cfg);
+    view->impl = impl; /* borrowed: never profile_del() a view */
+    view->core_size = dcp_profile_core_size(impl);
+    memcpy(view->consensus, dcp_profile_consensus(impl), (size_t)view->core_size + 1);
+    memcpy(view->null.ndist.nucltp.lprobs, dcp_profile_null_dist(impl), sizeof view->null.ndist.nucltp.lprobs);
+    memcpy(view->null.ndist.codonm.lprobs, dcp_profile_null_dist(impl) + IMM_NUCLT_SIZE,
+           sizeof view->null.ndist.codonm.lprobs);
+    memcpy(view->alt.insert_ndist.nucltp.lprobs, dcp_profile_insert_dist(impl), sizeof view->alt.insert_ndist.nucltp.lprobs);
+    memcpy(view->alt.insert_ndist.codonm.lprobs, dcp_profile_insert_dist(impl) + IMM_NUCLT_SIZE,
+           sizeof view->alt.insert_ndist.codonm.lprobs);
+    view->alt.match_ndists = malloc((size_t)view->core_size * sizeof *view->alt.match_ndists);
+    if (!view->alt.match_ndists) return fail(RC_ENOMEM, "alloc nuclt dists");
+    float const *md = dcp_profile_match_dist(impl);
+    for (unsigned k = 0; k < view->core_size; ++k)
+    {
+        struct nuclt_dist *d = view->alt.match_ndists + k;
+        nuclt_dist_init(d, view->code->nuclt);
+        memcpy(d->nucltp.lprobs, md + (size_t)k * DCP_NDIST, sizeof d->nucltp.lprobs);
+        memcpy(d->codonm.lprobs, md + (size_t)k * DCP_NDIST + IMM_NUCLT_SIZE, sizeof d->codonm.lprobs);
+    }
+    return RC_OK;
+}
+
+enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
+                         unsigned nseqs)
+{
+    struct profile_reader *reader = t->reader;
+    if (!reader || !seqs || nseqs == 0) return fail(RC_EINVAL, "thread has no reader or sequence");
+    if (t->id >= reader->npartitions) return fail(RC_EINVAL, "thread %u has no partition", t->id);
+    unsigned const n = reader->partition_size[t->id];
+    if (n == 0) return RC_OK;
+    if (!t->write_match_func) return fail(RC_EINVAL, "thread has no write_match_func");
+    enum rc rc = thread_prepare(t, tid);
+    if (rc) return rc;
+
+    /* protein_profile_setup(pp, size, ...) rejects the empty sequence for every profile (:112) */
+    size_t total = 0;
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        if (seqs[q].size == 0) return fail(RC_EINVAL, "sequence cannot be empty");
+        total += seqs[q].size;
+    }
+    /* encode once per batch (imm_task_setup does it per pair: scan_thread.c:51-55); the caller's
+     * buffers may be overwritten by its next fetch (scan.c:227-229), nothing here keeps them */
+    uint8_t *ids = malloc(total);
+    uint32_t *off = malloc(((size_t)nseqs + 1) * sizeof *off);
+    if (!ids || !off)
+    {
+        free(ids), free(off);
+        return fail(RC_ENOMEM, "alloc sequence batch");
+    }
+    off[0] = 0;
+    for (unsigned q = 0; q < nseqs && !rc; ++q)
+    {
+        uint8_t *one = dcp_host_seq_ids(&seqs[q], &rc);
+        if (one)
+        {
+            memcpy(ids + off[q], one, seqs[q].size);
+            free(one);
+        }
+        off[q + 1] = off[q] + seqs[q].size;
+    }
+    int drc = 0;
+    if (!rc && (drc = dcp_gpu_seqs_upload(t->gpu, ids, off, nseqs))) rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
+    free(ids);
+    struct dcp_scan_params prm = {t->multi_hits, t->hmmer3_compat, (float)t->lrt_threshold, 0, 0};
+    if ((double)prm.lrt_threshold != t->lrt_threshold && !rc)
+    {
+        /* the device filter compares in float32 like xmath_lrt's imm_float (scan_thread.c:121-123); a
+         * threshold that is not a float32 value would be rounded: keep every candidate at the next
+         * lower float and re-apply the caller's double below */
+        prm.lrt_threshold = nextafterf(prm.lrt_threshold, -INFINITY);
+    }
+    if (!rc && ((drc = dcp_gpu_scan(t->gpu, &prm)) || (drc = dcp_gpu_sync(t->gpu))))
+        rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
+
+    /* the LRT filter ran on the device: only hits come back, sorted by (seq, profile) */
+    unsigned nhits = 0;
+    struct dcp_hit *hits = NULL;
+    struct dcp_step *steps = NULL;
+    uint32_t *soff = NULL;
+    if (!rc)
+    {
+        drc = dcp_gpu_fetch_hits(t->gpu, NULL, 0, &nhits); /* count first */
+        if (drc && drc != DCP_ENOMEM) rc = fail((enum rc)drc, "fetch hits");
+        if (!rc && (uint64_t)nhits > (uint64_t)n * nseqs) rc = fail(RC_EFAIL, "more hits than pairs");
+    }
+    if (!rc && nhits)
+    {
+        hits = malloc((size_t)nhits * sizeof *hits);
+        if (!hits) rc = fail(RC_ENOMEM, "alloc hits");
+        if (!rc && (drc = dcp_gpu_fetch_hits(t->gpu, hits, nhits, &nhits))) rc = fail((enum rc)drc, "fetch hits");
+        uint64_t cap = 0;
+        for (unsigned h = 0; !rc && h < nhits; ++h)
+            cap += 2 * (uint64_t)seqs[hits[h].seq_idx].size + 2 * (uint64_t)dcp_profile_core_size(t->impls[hits[h].profile_idx]) + 16;
+        if (!rc && cap > UINT32_MAX) rc = fail(RC_ENOMEM, "too many path steps in one batch");
+        if (!rc)
+        {
+            steps = malloc((size_t)cap * sizeof *steps);
+            soff = malloc(((size_t)nhits + 1) * sizeof *soff);
+            if (!steps || !soff) rc = fail(RC_ENOMEM, "alloc paths");
+        }
+        if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, hits, nhits, t->multi_hits, t->hmmer3_compat, 0, steps,
+                                              (unsigned)cap, soff, NULL)))
+            rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
+        for (unsigned h = 0; !rc && h < nhits; ++h)
+        {
+            unsigned const q = hits[h].seq_idx;
+            imm_float const lrt = xmath_lrt_f32(hits[h].null_loglik, hits[h].alt_loglik);
+            if (!imm_lprob_is_finite(lrt) || lrt < t->lrt_threshold) continue; /* scan_thread.c:123 */
+            struct protein_profile view;
+            if ((rc = profile_view(t, hits[h].profile_idx, &view))) break;
+            /* strcpy(t->prod.profile_name, prof->accession); match_setup; write_product (:125-128) */
+            snprintf(t->prod.profile_name, sizeof t->prod.profile_name, "%s", view.super.accession);
+            if (seq_ids) t->prod.seq_id = seq_ids[q];
+            t->prod.null_loglik = (double)hits[h].null_loglik;
+            t->prod.alt_loglik = (double)hits[h].alt_loglik;
+            t->null.prod.loglik = hits[h].null_loglik;
+            t->alt.prod.loglik = hits[h].alt_loglik;
+            rc = dcp_host_path_assign(&t->alt.prod.path, steps + soff[h], soff[h + 1] - soff[h]);
+            if (!rc)
+            {
+                match_setup((struct match *)&t->match, &view.super);
+                rc = prod_fwrite(&t->prod, &seqs[q], &t->alt.prod.path, t->id, t->write_match_func,
+                                 (struct match *)&t->match);
+                t->match.pro.match.profile = NULL; /* the view dies here */
+            }
+            free(view.alt.match_ndists);
+        }
+    }
+    free(soff);
+    free(steps);
+    free(hits);
+    free(off);
+    return rc;
+}
+
+enum rc thread_run(struct scan_thread *t, int tid)
+{
+    if (!t->reader || !t->seq) return fail(RC_EINVAL, "thread has no reader or sequence");
+    int64_t id = t->prod.seq_id;
+    return thread_run_batch(t, tid, t->seq, &id, 1);
+}
+
+/* ============================== scan loop (src/server/scan.c:215-269) ========================== */
+enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned nthreads, scan_next_seq_func_t next_seq,
+                        void *arg)
+{
+    if (!db_filename || !next_seq) return fail(RC_EINVAL, "bad scan arguments");
+    if (nthreads == 0 || nthreads > NUM_THREADS) return fail(RC_EINVAL, "bad number of threads");
+    unsigned const batch = cfg.batch ? cfg.batch : 1;
+
+    /* prepare_readers (scan.c:45-74) */
+    FILE *fp = fopen(db_filename, "rb");
+    if (!fp) return fail(RC_EIO, "failed to open database");
+    struct protein_db_reader *db = calloc(1, sizeof *db);
+    struct profile_reader *reader = calloc(1, sizeof *reader);
+    struct scan_thread *th = NULL;
+    struct imm_seq *bseq = NULL;
+    int64_t *bid = NULL;
+    char **btext = NULL;
+    bool db_open = false, reader_open = false;
+    unsigned nparts = 0;
+    enum rc rc = RC_OK;
+    if (!db || !reader)
+    {
+        rc = fail(RC_ENOMEM, "alloc scan");
+        goto cleanup;
+    }
+    if ((rc = protein_db_reader_open(db, fp))) goto cleanup;
+    db_open = true;
+    rc = cfg.balance_by_cells ? profile_reader_setup_balanced(reader, &db->super, nthreads)
+                              : profile_reader_setup(reader, &db->super, nthreads);
+    if (rc) goto cleanup;
+    reader_open = true;
+    nparts = profile_reader_npartitions(reader);
+    struct imm_abc const *abc = &db->nuclt.super;
+
+    if ((rc = prod_fopen(nparts))) goto cleanup;
+    th = calloc(nparts ? nparts : 1, sizeof *th);
+    bseq = malloc((size_t)batch * sizeof *bseq);
+    bid = malloc((size_t)batch * sizeof *bid);
+    btext = calloc(batch, sizeof *btext);
+    if (!th || !bseq || !bid || !btext)
+    {
+        rc = fail(RC_ENOMEM, "alloc scan");
+        goto cleanup;
+    }
+    for (unsigned i = 0; i < nparts; ++i)
+    {
+        thread_init(&th[i], i, reader, cfg.multi_hits, cfg.hmmer3_compat, cfg.lrt_threshold, protein_match_write_func);
+        thread_setup_job(&th[i], imm_abc_typeid(abc), reader->profile_typeid, cfg.scan_id);
+    }
+
+    for (bool more = true; more && !rc;)
+    {
+        /* prefetch up to `batch` sequences; each is copied, the source may reuse its buffer (scan.c:227-229) */
+        unsigned nb = 0;
+        while (nb < batch)
+        {
+            struct scan_seq s = {0, NULL};
+            enum rc r = next_seq(arg, &s);
+            if (r == RC_END)
+            {
+                more = false;
+                break;
+            }
+            if (r || !s.data)
+            {
+                rc = r ? r : fail(RC_EINVAL, "sequence source returned no data");
+                break;
+            }
+            free(btext[nb]);
+            btext[nb] = strdup(s.data);
+            if (!btext[nb])
+            {
+                rc = fail(RC_ENOMEM, "alloc sequence");
+                break;
+            }
+            bseq[nb] = imm_seq(imm_str(btext[nb]), abc);
+            bid[nb] = s.id;
+            ++nb;
+        }
+        if (rc || nb == 0) break;
+        enum rc shared = RC_OK;
+#pragma omp parallel for schedule(static, 1) num_threads(nparts)
+        for (unsigned i = 0; i < nparts; ++i)
+        {
+            enum rc r = thread_run_batch(&th[i], (int)i, bseq, bid, nb);
+            if (r)
+            {
+#pragma omp atomic write
+                shared = r; /* scan.c:246-248: a failing partition fails the scan */
+            }
+        }
+        rc = shared;
+    }
+    if (!rc) rc = prod_fclose(); /* work_finishup: header + every thread's rows, in thread order */
+
+cleanup:
+    if (rc) prod_fcleanup();
+    for (unsigned i = 0; th && i < nparts; ++i)
+        thread_cleanup(&th[i]);
+    for (unsigned i = 0; btext && i < batch; ++i)
+        free(btext[i]);
+    free(btext), free(bid), free(bseq), free(th);
+    if (reader_open) profile_reader_del(reader);
+    if (db_open) db_reader_close(&db->super);
+    free(reader), free(db);
+    fclose(fp);
+    return rc;
+}
+
+struct list_source
+{
+    struct scan_seq const *seqs;
+    unsigned n, next;
+};
+
+static enum rc list_next(void *arg, struct scan_seq *seq)
+{
+    struct list_source *src = arg;
+    if (src->next >= src->n) return RC_END;
+    *seq = src->seqs[src->next++];
+    return RC_OK;
+}
+
+enum rc scan_run_local(char const *db_filename, struct scan_seq const *seqs, unsigned nseqs, unsigned nthreads,
+                       bool multi_hits, bool hmmer3_compat, double lrt_threshold, int64_t scan_id, unsigned batch,
+                       FILE *prods)
+{
+    if (!seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
+    struct list_source src = {seqs, nseqs, 0};
+    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true};
+    enum rc rc = scan_run_source(db_filename, cfg, nthreads, list_next, &src);
+    if (rc) return rc;
+    char buf[1 << 16];
+    size_t n;
+    FILE *fp = prod_final_fp();
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0)
+        if (fwrite(buf, 1, n, prods) != n) rc = fail(RC_EIO, "fail to finish product");
+    prod_final_cleanup();
+    return rc;
+}

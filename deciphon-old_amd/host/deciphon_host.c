@@ -1,23 +1,22 @@
 /*
- * deciphon_host.c -- C11 host orchestration of the scan path over the HIP C-ABI.
+ * deciphon_host.c -- C11 host layer, part 1: the imm subset and the model objects
+ * (include/deciphon_host.h sections "core", "imm subset", "model").
  *
- * Implements include/deciphon_host.h: the reference's model/db/server entry points
- * for this path (names, argument meaning, return codes) with every score and path
- * computed on the device through dcp_gpu.h.  Reference files followed (behaviour,
- * not code): src/model/protein_profile.c:134-331, src/model/profile.c,
- * src/model/protein_state.c, src/model/protein_codec.c, src/db/profile_reader.c:54-168,
- * src/server/scan_thread.c:9-135, src/server/prod.c:13-41,153-181.
+ * Keeps the reference's names, argument meaning and return codes; every score and path is computed
+ * on the device through dcp_gpu.h.  Reference files followed (behaviour, not code):
+ * src/model/protein_profile.c, src/model/profile.c, src/model/protein_model.c:49-184,
+ * src/model/protein_state.c, src/model/protein_codec.c, src/model/protein_h3reader.c:18-72,
+ * src/model/nuclt_dist.c, src/model/standard_profile.c.
  */
 #include "deciphon_host.h"
+#include "host_internal.h"
 
-#include <assert.h>
-#include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 
-/* ---- logging: errors are reported where they are detected and returned -------------------- */
-static enum rc fail(enum rc rc, char const *fmt, ...)
+/* ---- logging: errors are reported where they are detected and returned (logging.h:32-72) ------- */
+enum rc dcp_host_fail(enum rc rc, char const *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -27,28 +26,34 @@ static enum rc fail(enum rc rc, char const *fmt, ...)
     va_end(ap);
     return rc;
 }
+#define fail dcp_host_fail
 
-/* ---- core ----------------------------------------------------------------------------------- */
-unsigned xmath_partition_size(unsigned nelems, unsigned nparts, unsigned idx)
+char const *rc_string(enum rc rc)
 {
-    unsigned size = (nelems + nparts - 1) / nparts;
-    assert(nelems >= size * idx);
-    return size < nelems - size * idx ? size : nelems - size * idx;
+    static char const *const names[] = {"RC_OK",     "RC_END",    "RC_EFAIL", "RC_EINVAL", "RC_EIO",
+                                        "RC_ENOMEM", "RC_EPARSE", "RC_EAPI",  "RC_EHTTP"};
+    return (unsigned)rc < sizeof names / sizeof names[0] ? names[rc] : "invalid return code";
 }
 
-float xmath_lrt_f32(float null_loglik, float alt_loglik) { return dcp_lrt(null_loglik, alt_loglik); }
-
-/* ---- alphabets / sequences -------------------------------------------------------------------- */
-struct imm_nuclt const imm_dna_iupac = {{IMM_DNA, "ACGT", 'X'}};
-struct imm_amino const imm_amino_iupac = {{IMM_AMINO, "ACDEFGHIKLMNPQRSTVWY", 'X'}};
+/* ---- alphabets / sequences --------------------------------------------------------------------- */
+#define ABC(sz, syms, tid) {sz, syms, sz, 'X', {tid, NULL}}
+struct imm_dna const imm_dna_iupac = {{ABC(4, "ACGT", IMM_DNA)}};
+struct imm_rna const imm_rna_iupac = {{ABC(4, "ACGU", IMM_RNA)}};
+struct imm_amino const imm_amino_iupac = {ABC(20, "ACDEFGHIKLMNPQRSTVWY", IMM_AMINO)};
 
 void imm_nuclt_code_init(struct imm_nuclt_code *code, struct imm_nuclt const *nuclt)
 {
-    code->abc = &nuclt->super;
+    code->super.abc = &nuclt->super;
     code->nuclt = nuclt;
 }
 
-unsigned imm_abc_any_symbol_id(struct imm_abc const *abc) { return (unsigned)strlen(abc->symbols); }
+int imm_abc_symbol_idx(struct imm_abc const *abc, char symbol)
+{
+    if (symbol == '\0') return -1;
+    if (symbol == abc->any_symbol) return (int)abc->any_symbol_id;
+    char const *p = memchr(abc->symbols, symbol, abc->size);
+    return p ? (int)(p - abc->symbols) : -1;
+}
 
 char const *imm_abc_typeid_name(enum imm_abc_typeid typeid)
 {
@@ -63,18 +68,10 @@ struct imm_seq imm_seq(struct imm_str str, struct imm_abc const *abc)
     return (struct imm_seq){str.size, str.data, abc};
 }
 
-unsigned imm_seq_size(struct imm_seq const *seq) { return seq->size; }
-
 struct imm_seq imm_subseq(struct imm_seq const *seq, unsigned start, unsigned size)
 {
     assert(start + size <= seq->size);
     return (struct imm_seq){size, seq->str + start, seq->abc};
-}
-
-static unsigned symbol_id(struct imm_abc const *abc, char c)
-{
-    char const *p = strchr(abc->symbols, c);
-    return p && c ? (unsigned)(p - abc->symbols) : imm_abc_any_symbol_id(abc);
 }
 
 struct imm_codon imm_codon(struct imm_nuclt const *nuclt, unsigned a, unsigned b, unsigned c)
@@ -82,16 +79,28 @@ struct imm_codon imm_codon(struct imm_nuclt const *nuclt, unsigned a, unsigned b
     return (struct imm_codon){nuclt, a, b, c};
 }
 
+struct imm_codon imm_codon_any(struct imm_nuclt const *nuclt)
+{
+    unsigned const any = imm_abc_any_symbol_id(&nuclt->super);
+    return imm_codon(nuclt, any, any, any);
+}
+
+static unsigned sym_or_any(struct imm_abc const *abc, char c)
+{
+    int const i = imm_abc_symbol_idx(abc, c);
+    return i < 0 ? abc->any_symbol_id : (unsigned)i;
+}
+
 struct imm_codon imm_codon_from_symbols(struct imm_nuclt const *nuclt, char const sym[3])
 {
-    return imm_codon(nuclt, symbol_id(&nuclt->super, sym[0]), symbol_id(&nuclt->super, sym[1]),
-                     symbol_id(&nuclt->super, sym[2]));
+    struct imm_abc const *abc = &nuclt->super;
+    return imm_codon(nuclt, sym_or_any(abc, sym[0]), sym_or_any(abc, sym[1]), sym_or_any(abc, sym[2]));
 }
 
 static char codon_sym(struct imm_codon const *codon, unsigned id)
 {
     struct imm_abc const *abc = &codon->nuclt->super;
-    return id < imm_abc_any_symbol_id(abc) ? abc->symbols[id] : abc->any_symbol;
+    return id < abc->size ? abc->symbols[id] : abc->any_symbol;
 }
 char imm_codon_asym(struct imm_codon const *codon) { return codon_sym(codon, codon->a); }
 char imm_codon_bsym(struct imm_codon const *codon) { return codon_sym(codon, codon->b); }
@@ -105,7 +114,30 @@ char imm_gc_decode(unsigned table, struct imm_codon codon)
     return dcp_gc_decode(ids);
 }
 
-/* ---- task / prod / path ------------------------------------------------------------------------ */
+/* ---- rnd / lprob --------------------------------------------------------------------------------- */
+struct imm_rnd imm_rnd(uint64_t seed)
+{
+    struct imm_rnd r;
+    dcp_rnd_seed(r.data, seed);
+    return r;
+}
+
+double imm_rnd_dbl(struct imm_rnd *rnd) { return dcp_rnd_next(rnd->data); }
+
+void imm_lprob_sample(struct imm_rnd *rnd, unsigned len, imm_float *lprobs)
+{
+    for (unsigned i = 0; i < len; ++i)
+        lprobs[i] = (imm_float)log(imm_rnd_dbl(rnd));
+}
+
+void imm_lprob_normalize(unsigned len, imm_float *lprobs) { dcp_lprob_normalize(len, lprobs); }
+
+struct imm_frame_epsilon imm_frame_epsilon(imm_float epsilon)
+{
+    return (struct imm_frame_epsilon){imm_log(epsilon), imm_log(1 - epsilon)};
+}
+
+/* ---- task / prod / path ---------------------------------------------------------------------------- */
 struct imm_task *imm_task_new(struct imm_dp const *dp)
 {
     struct imm_task *t = malloc(sizeof *t);
@@ -131,25 +163,57 @@ enum imm_rc imm_task_setup(struct imm_task *task, struct imm_seq const *seq)
 
 void imm_task_del(struct imm_task const *task) { free((void *)task); }
 
-struct imm_prod imm_prod(void) { return (struct imm_prod){{NULL, 0, 0}, NAN}; }
+struct imm_prod imm_prod(void) { return (struct imm_prod){{NULL, 0, 0}, NAN, 0}; }
 
 void imm_prod_reset(struct imm_prod *prod)
 {
     prod->path.nsteps = 0;
     prod->loglik = NAN;
+    prod->mseconds = 0;
 }
 
 void imm_prod_del(struct imm_prod const *prod) { free(prod->path.steps); }
 
-unsigned imm_path_nsteps(struct imm_path const *path) { return path->nsteps; }
-
-struct imm_step const *imm_path_step(struct imm_path const *path, unsigned idx)
+enum rc dcp_host_path_assign(struct imm_path *path, struct dcp_step const *steps, unsigned n)
 {
-    assert(idx < path->nsteps);
-    return path->steps + idx;
+    if (path->capacity < n)
+    {
+        struct imm_step *p = realloc(path->steps, (size_t)n * sizeof *p);
+        if (!p) return fail(RC_ENOMEM, "alloc path");
+        path->steps = p;
+        path->capacity = n;
+    }
+    for (unsigned i = 0; i < n; ++i)
+        path->steps[i] = (struct imm_step){steps[i].state_id, steps[i].seqlen};
+    path->nsteps = n;
+    return RC_OK;
 }
 
-bool imm_lprob_is_finite(imm_float x) { return isfinite(x); }
+/* symbol ids 0..3 of a sequence over its own 4-letter alphabet (DNA or RNA); NULL + EINVAL for a symbol
+ * outside it.  (What imm does with the any-symbol in a frame state's emission is not pinned by anything in
+ * the reference tree -- SURVEY.md Appendix C -- so it is rejected, not guessed.) */
+uint8_t *dcp_host_seq_ids(struct imm_seq const *seq, enum rc *rc)
+{
+    uint8_t *ids = malloc(seq->size ? seq->size : 1);
+    if (!ids)
+    {
+        *rc = fail(RC_ENOMEM, "alloc sequence");
+        return NULL;
+    }
+    for (unsigned i = 0; i < seq->size; ++i)
+    {
+        int const id = imm_abc_symbol_idx(seq->abc, seq->str[i]);
+        if (id < 0 || id > 3 || seq->abc->size != 4)
+        {
+            *rc = fail(RC_EINVAL, "symbol '%c' at %u is not one of \"%s\"", seq->str[i], i, seq->abc->symbols);
+            free(ids);
+            return NULL;
+        }
+        ids[i] = (uint8_t)id;
+    }
+    *rc = RC_OK;
+    return ids;
+}
 
 /* one shared device context for single-pair imm_dp_viterbi calls (library-level use, as the
  * reference's tests do); thread_run owns one context per partition instead */
@@ -173,19 +237,9 @@ static dcp_gpu_ctx *shared_ctx(void)
     return g_ctx;
 }
 
-static enum rc path_assign(struct imm_path *path, struct dcp_step const *steps, unsigned n)
+void dcp_host_forget_profile(dcp_profile *impl)
 {
-    if (path->capacity < n)
-    {
-        struct imm_step *p = realloc(path->steps, (size_t)n * sizeof *p);
-        if (!p) return fail(RC_ENOMEM, "alloc path");
-        path->steps = p;
-        path->capacity = n;
-    }
-    for (unsigned i = 0; i < n; ++i)
-        path->steps[i] = (struct imm_step){steps[i].state_id, steps[i].seqlen};
-    path->nsteps = n;
-    return RC_OK;
+    if (impl && g_ctx_db == impl) g_ctx_db = NULL;
 }
 
 enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struct imm_prod *prod)
@@ -195,15 +249,12 @@ enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struc
     struct imm_seq const *seq = task->seq;
     if (!prof || !prof->impl)
     {
-        fail(RC_EINVAL, "profile holds no model (call protein_profile_sample / _from_params first)");
+        fail(RC_EINVAL, "dp holds no model (protein_profile_sample / _absorb / _unpack first)");
         return IMM_FAILURE;
     }
-    if (prof->seq_size == 0 || prof->seq_size != seq->size)
+    if (seq->size == 0)
     {
-        /* imm keeps whatever transitions the last protein_profile_setup() wrote; the device path
-         * derives them from the sequence length, so the two must agree */
-        fail(RC_EINVAL, "protein_profile_setup(%u) does not match the sequence length %u", prof->seq_size,
-             seq->size);
+        fail(RC_EINVAL, "sequence cannot be empty");
         return IMM_FAILURE;
     }
     dcp_gpu_ctx *ctx = shared_ctx();
@@ -212,15 +263,27 @@ enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struc
         fail(RC_EFAIL, "no HIP device: imm_dp_viterbi has no CPU implementation here");
         return IMM_FAILURE;
     }
+    enum rc rc = RC_OK;
+    uint8_t *ids = dcp_host_seq_ids(seq, &rc);
+    if (!ids) return IMM_FAILURE;
     if (g_ctx_db != prof->impl)
     {
         dcp_profile *one[1] = {prof->impl};
-        if (dcp_gpu_db_upload(ctx, one, 1, 0)) return IMM_FAILURE;
+        g_ctx_db = NULL;
+        if (dcp_gpu_db_upload(ctx, one, 1, 0))
+        {
+            free(ids);
+            return IMM_FAILURE;
+        }
         g_ctx_db = prof->impl;
     }
     uint32_t off[2] = {0, seq->size};
-    if (dcp_gpu_seqs_upload_text(ctx, seq->str, off, 1)) return IMM_FAILURE;
-    struct dcp_scan_params prm = {prof->multi_hits, prof->hmmer3_compat, 10.0f, 1, 1 /* row sweep */};
+    int drc = dcp_gpu_seqs_upload(ctx, ids, off, 1);
+    free(ids);
+    if (drc) return IMM_FAILURE;
+    /* the transitions the profile holds NOW: protein_profile_setup's, or the LOG1 defaults */
+    if (dcp_gpu_seqs_set_xtrans(ctx, prof->xtrans, 1)) return IMM_FAILURE;
+    struct dcp_scan_params prm = {1, 0, 10.0f, 1, 1 /* row sweep */};
     if (dcp_gpu_scan(ctx, &prm) || dcp_gpu_sync(ctx)) return IMM_FAILURE;
     float nul = NAN, alt = NAN;
     if (dcp_gpu_fetch_scores(ctx, &nul, &alt)) return IMM_FAILURE;
@@ -231,10 +294,9 @@ enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struc
     if (!steps) return IMM_FAILURE;
     uint32_t soff[2] = {0, 0};
     float traced = NAN;
-    int rc = dcp_gpu_trace_paths(ctx, &pair, 1, prof->multi_hits, prof->hmmer3_compat, dp->null_model, steps, cap,
-                                 soff, &traced);
+    drc = dcp_gpu_trace_paths(ctx, &pair, 1, 1, 0, dp->null_model, steps, cap, soff, &traced);
     enum imm_rc out = IMM_FAILURE;
-    if (!rc && !path_assign(&prod->path, steps, soff[1]))
+    if (!drc && !dcp_host_path_assign(&prod->path, steps, soff[1]))
     {
         prod->loglik = dp->null_model ? nul : alt;
         out = traced == prod->loglik ? IMM_OK : IMM_FAILURE; /* the trace recomputes the score bit for bit */
@@ -243,7 +305,72 @@ enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struc
     return out;
 }
 
-/* ---- protein state ----------------------------------------------------------------------------- */
+/* ---- imm_dp: a handle on the owning profile ------------------------------------------------------- */
+void imm_dp_init(struct imm_dp *dp, struct imm_code const *code)
+{
+    dp->owner = NULL;
+    dp->null_model = 0;
+    dp->code = code;
+}
+
+void imm_dp_del(struct imm_dp const *dp) { (void)dp; }
+
+/* The 13 special transitions, addressed like protein_profile_setup addresses them
+ * (src/model/protein_profile.c:186-214): by (source, destination) state index. */
+unsigned imm_dp_trans_idx(struct imm_dp *dp, unsigned src, unsigned dst)
+{
+    struct protein_profile const *p = dp->owner;
+    if (!p) return UINT_MAX;
+    if (dp->null_model) return src == p->null.R && dst == p->null.R ? DCP_HOST_X_RR : UINT_MAX;
+    unsigned const S = p->alt.S, N = p->alt.N, B = p->alt.B, E = p->alt.E, J = p->alt.J, C = p->alt.C, T = p->alt.T;
+    if (src == S && dst == B) return DCP_HOST_X_SB;
+    if (src == S && dst == N) return DCP_HOST_X_SN;
+    if (src == N && dst == N) return DCP_HOST_X_NN;
+    if (src == N && dst == B) return DCP_HOST_X_NB;
+    if (src == E && dst == T) return DCP_HOST_X_ET;
+    if (src == E && dst == C) return DCP_HOST_X_EC;
+    if (src == C && dst == C) return DCP_HOST_X_CC;
+    if (src == C && dst == T) return DCP_HOST_X_CT;
+    if (src == E && dst == B) return DCP_HOST_X_EB;
+    if (src == E && dst == J) return DCP_HOST_X_EJ;
+    if (src == J && dst == J) return DCP_HOST_X_JJ;
+    if (src == J && dst == B) return DCP_HOST_X_JB;
+    return UINT_MAX;
+}
+
+void imm_dp_change_trans(struct imm_dp *dp, unsigned trans_idx, imm_float lprob)
+{
+    assert(dp->owner && trans_idx < DCP_NXTRANS);
+    if (dp->owner && trans_idx < DCP_NXTRANS) dp->owner->xtrans[trans_idx] = lprob;
+}
+
+void imm_dp_write_dot(struct imm_dp const *dp, FILE *fp, imm_state_name *name)
+{
+    /* the alt model's core as a Graphviz digraph: enough for a human to look at, nothing parses it */
+    struct protein_profile const *p = dp->owner;
+    fprintf(fp, "digraph hmm {\n");
+    if (p && p->impl && !dp->null_model)
+    {
+        float const *t8 = dcp_profile_trans8(p->impl);
+        unsigned const M = p->core_size;
+        char a[IMM_STATE_NAME_SIZE], b[IMM_STATE_NAME_SIZE];
+        for (unsigned k = 0; k < M; ++k)
+        {
+            name(PROTEIN_MATCH_STATE | (k + 1), a);
+            fprintf(fp, "B -> %s [label=%.4f];\n", a, (double)t8[0 * M + k]);
+            if (k + 1 < M)
+            {
+                name(PROTEIN_MATCH_STATE | (k + 2), b);
+                fprintf(fp, "%s -> %s [label=%.4f];\n", a, b, (double)t8[1 * M + k + 1]);
+            }
+        }
+    }
+    else if (p && dp->null_model)
+        fprintf(fp, "R -> R [label=%.4f];\n", (double)p->xtrans[DCP_HOST_X_RR]);
+    fprintf(fp, "}\n");
+}
+
+/* ---- protein state --------------------------------------------------------------------------------- */
 static unsigned state_msb(unsigned id) { return id & (3U << (BITS_PER_PROFILE_TYPEID - 2)); }
 bool protein_state_is_match(unsigned id) { return state_msb(id) == PROTEIN_MATCH_STATE; }
 bool protein_state_is_insert(unsigned id) { return state_msb(id) == PROTEIN_INSERT_STATE; }
@@ -263,18 +390,132 @@ char const *profile_typeid_name(enum profile_typeid typeid)
     return (unsigned)typeid < 3 ? names[typeid] : "unknown";
 }
 
-/* ---- profile / protein_profile ------------------------------------------------------------------ */
-struct protein_cfg protein_cfg(enum entry_dist entry_dist, imm_float epsilon)
+/* ---- protein_model: collects the amino-acid level parameters ------------------------------------------ */
+void protein_model_init(struct protein_model *m, struct imm_amino const *amino, struct imm_nuclt_code const *code,
+                        struct protein_cfg cfg, imm_float const null_lprobs[IMM_AMINO_SIZE])
 {
-    assert(epsilon >= 0.0f && epsilon <= 1.0f);
-    return (struct protein_cfg){entry_dist, epsilon};
+    m->amino = amino;
+    m->code = code;
+    m->cfg = cfg;
+    m->core_size = 0;
+    m->consensus[0] = '\0';
+    memcpy(m->null.lprobs, null_lprobs, sizeof m->null.lprobs);
+    m->alt.node_idx = UINT_MAX; /* "setup not called yet" (protein_model.c:131,134) */
+    m->alt.match_lprobs = NULL;
+    m->alt.trans_idx = UINT_MAX;
+    m->alt.trans = NULL;
+    protein_xtrans_init(&m->xtrans);
 }
 
+enum rc protein_model_setup(struct protein_model *m, unsigned core_size)
+{
+    if (core_size == 0) return fail(RC_EINVAL, "`core_size` cannot be zero");
+    if (core_size > PROTEIN_MODEL_CORE_SIZE_MAX) return fail(RC_EINVAL, "`core_size` is too big");
+    void *nodes = realloc(m->alt.match_lprobs, (size_t)core_size * sizeof *m->alt.match_lprobs);
+    if (!nodes) return fail(RC_ENOMEM, "failed to alloc nodes");
+    m->alt.match_lprobs = nodes;
+    void *trans = realloc(m->alt.trans, ((size_t)core_size + 1) * sizeof *m->alt.trans);
+    if (!trans) return fail(RC_ENOMEM, "failed to alloc trans");
+    m->alt.trans = trans;
+    m->core_size = core_size;
+    m->consensus[core_size] = '\0';
+    m->alt.node_idx = 0;
+    m->alt.trans_idx = 0;
+    return RC_OK;
+}
+
+static bool model_setup_called(struct protein_model const *m) { return m->core_size > 0; }
+static bool model_complete(struct protein_model const *m)
+{
+    return model_setup_called(m) && m->alt.node_idx == m->core_size && m->alt.trans_idx == m->core_size + 1;
+}
+
+enum rc protein_model_add_node(struct protein_model *m, imm_float const lp[IMM_AMINO_SIZE], char consensus)
+{
+    if (!model_setup_called(m)) return fail(RC_EFAIL, "must call protein_model_setup first");
+    if (m->alt.node_idx == m->core_size) return fail(RC_EFAIL, "reached limit of nodes");
+    m->consensus[m->alt.node_idx] = consensus;
+    memcpy(m->alt.match_lprobs[m->alt.node_idx], lp, sizeof m->alt.match_lprobs[0]);
+    m->alt.node_idx++;
+    return RC_OK;
+}
+
+enum rc protein_model_add_trans(struct protein_model *m, struct protein_trans trans)
+{
+    if (!model_setup_called(m)) return fail(RC_EFAIL, "must call protein_model_setup first");
+    if (m->alt.trans_idx == m->core_size + 1) return fail(RC_EFAIL, "reached limit of transitions");
+    m->alt.trans[m->alt.trans_idx++] = trans;
+    return RC_OK;
+}
+
+void protein_model_del(struct protein_model const *m)
+{
+    free(m->alt.match_lprobs);
+    free(m->alt.trans);
+}
+
+struct imm_amino const *protein_model_amino(struct protein_model const *m) { return m->amino; }
+struct imm_nuclt const *protein_model_nuclt(struct protein_model const *m) { return m->code->nuclt; }
+
+/* ---- profile ------------------------------------------------------------------------------------------ */
+void profile_init(struct profile *prof, char const *accession, struct imm_code const *code,
+                  struct profile_vtable vtable, imm_state_name *state_name)
+{
+    prof->vtable = vtable;
+    snprintf(prof->accession, sizeof prof->accession, "%s", accession ? accession : "");
+    prof->state_name = state_name;
+    prof->code = code;
+}
+
+void profile_del(struct profile *prof)
+{
+    if (prof && prof->vtable.del) prof->vtable.del(prof);
+}
+enum rc profile_unpack(struct profile *prof, struct lip_file *file) { return prof->vtable.unpack(prof, file); }
+int profile_typeid(struct profile const *prof) { return prof->vtable.typeid; }
+struct imm_dp const *profile_null_dp(struct profile const *prof) { return prof->vtable.null_dp(prof); }
+struct imm_dp const *profile_alt_dp(struct profile const *prof) { return prof->vtable.alt_dp(prof); }
+
+/* ---- nuclt_dist <-> the compact profile's 129-float rows ------------------------------------------------ */
+static void ndist_from_row(struct nuclt_dist *d, float const row[DCP_NDIST])
+{
+    memcpy(d->nucltp.lprobs, row, sizeof d->nucltp.lprobs);
+    memcpy(d->codonm.lprobs, row + IMM_NUCLT_SIZE, sizeof d->codonm.lprobs);
+}
+
+static void ndist_to_row(struct nuclt_dist const *d, float row[DCP_NDIST])
+{
+    memcpy(row, d->nucltp.lprobs, sizeof d->nucltp.lprobs);
+    memcpy(row + IMM_NUCLT_SIZE, d->codonm.lprobs, sizeof d->codonm.lprobs);
+}
+
+enum rc nuclt_dist_pack(struct nuclt_dist const *ndist, struct lip_file *file)
+{
+    if (!lip_write_array_size(file, 2)) return RC_EFAIL;
+    if (imm_nuclt_lprob_pack(&ndist->nucltp, file)) return RC_EFAIL;
+    if (imm_codon_marg_pack(&ndist->codonm, file)) return RC_EFAIL;
+    return RC_OK;
+}
+
+enum rc nuclt_dist_unpack(struct nuclt_dist *ndist, struct lip_file *file)
+{
+    unsigned size = 0;
+    if (!lip_read_array_size(file, &size) || size != 2) return RC_EFAIL;
+    if (imm_nuclt_lprob_unpack(&ndist->nucltp, file)) return RC_EFAIL;
+    if (imm_codon_marg_unpack(&ndist->codonm, file)) return RC_EFAIL;
+    return RC_OK;
+}
+
+/* ---- protein_profile ------------------------------------------------------------------------------------- */
 static void protein_del(struct profile *prof)
 {
     if (!prof) return;
     struct protein_profile *p = (struct protein_profile *)prof;
-    if (g_ctx_db == p->impl) g_ctx_db = NULL;
+    free(p->alt.match_ndists);
+    p->alt.match_ndists = NULL;
+    imm_dp_del(&p->null.dp);
+    imm_dp_del(&p->alt.dp);
+    dcp_host_forget_profile(p->impl);
     dcp_profile_del(p->impl);
     p->impl = NULL;
 }
@@ -286,82 +527,112 @@ static struct imm_dp const *protein_alt_dp(struct profile const *prof)
 {
     return &((struct protein_profile const *)prof)->alt.dp;
 }
-
-void profile_del(struct profile *prof)
+static enum rc protein_unpack(struct profile *prof, struct lip_file *file)
 {
-    if (prof && prof->vtable.del) prof->vtable.del(prof);
-}
-int profile_typeid(struct profile const *prof) { return prof->vtable.typeid; }
-struct imm_dp const *profile_null_dp(struct profile const *prof) { return prof->vtable.null_dp(prof); }
-struct imm_dp const *profile_alt_dp(struct profile const *prof) { return prof->vtable.alt_dp(prof); }
-
-/* ---- standard_profile: typed shell (src/model/standard_profile.c:45-51, standard_state.c:5-10) --- */
-static void standard_del(struct profile *prof) { (void)prof; }
-static struct imm_dp const *standard_null_dp(struct profile const *prof)
-{
-    return &((struct standard_profile const *)prof)->dp.null;
-}
-static struct imm_dp const *standard_alt_dp(struct profile const *prof)
-{
-    return &((struct standard_profile const *)prof)->dp.alt;
-}
-unsigned standard_state_name(unsigned id, char name[IMM_STATE_NAME_SIZE])
-{
-    assert(id <= UINT16_MAX);
-    return (unsigned)snprintf(name, IMM_STATE_NAME_SIZE, "S%u", id);
-}
-void standard_profile_init(struct standard_profile *p, char const *accession, struct imm_nuclt_code const *code)
-{
-    memset(p, 0, sizeof *p);
-    p->super.vtable = (struct profile_vtable){PROFILE_STANDARD, standard_del, standard_null_dp, standard_alt_dp};
-    snprintf(p->super.accession, sizeof p->super.accession, "%s", accession ? accession : "");
-    p->super.state_name = standard_state_name;
-    p->super.code = code;
-    p->dp.null = (struct imm_dp){NULL, 1};
-    p->dp.alt = (struct imm_dp){NULL, 0};
+    return protein_profile_unpack((struct protein_profile *)prof, file);
 }
 
 void protein_profile_init(struct protein_profile *p, char const *accession, struct imm_amino const *amino,
                           struct imm_nuclt_code const *code, struct protein_cfg cfg)
 {
-    memset(p, 0, sizeof *p);
-    p->super.vtable = (struct profile_vtable){PROFILE_PROTEIN, protein_del, protein_null_dp, protein_alt_dp};
-    snprintf(p->super.accession, sizeof p->super.accession, "%s", accession ? accession : "");
-    p->super.state_name = protein_state_name;
-    p->super.code = code;
+    struct profile_vtable const vtable = {PROFILE_PROTEIN, protein_del, protein_unpack, protein_null_dp,
+                                          protein_alt_dp};
+    profile_init(&p->super, accession, &code->super, vtable, protein_state_name);
     p->amino = amino;
     p->code = code;
     p->cfg = cfg;
-    p->null.dp = (struct imm_dp){p, 1};
-    p->alt.dp = (struct imm_dp){p, 0};
-    /* state indices as imm_state_idx reports them after the HMM -> DP compile: the null model has
-     * the single state R; the alt model's specials were added first (protein_model.c:227-233) */
+    p->eps = imm_frame_epsilon(cfg.epsilon);
+    p->core_size = 0;
+    p->consensus[0] = '\0';
+    imm_dp_init(&p->null.dp, &code->super);
+    imm_dp_init(&p->alt.dp, &code->super);
+    p->null.dp.owner = p->alt.dp.owner = p;
+    p->null.dp.null_model = 1;
+    nuclt_dist_init(&p->null.ndist, code->nuclt);
+    nuclt_dist_init(&p->alt.insert_ndist, code->nuclt);
+    p->alt.match_ndists = NULL;
+    /* state indices as imm_state_idx reports them after the HMM -> DP compile: the null model has the
+     * single state R; the alt model's specials were added first (protein_model.c:227-233) */
     p->null.R = 0;
     p->alt.S = 0, p->alt.N = 1, p->alt.B = 2, p->alt.E = 3, p->alt.J = 4, p->alt.C = 5, p->alt.T = 6;
+    p->impl = NULL;
+    for (int i = 0; i < DCP_NXTRANS; ++i)
+        p->xtrans[i] = IMM_LPROB_ONE;
 }
 
 enum rc protein_profile_setup(struct protein_profile *prof, unsigned seq_size, bool multi_hits, bool hmmer3_compat)
 {
+    /* the 13 values protein_profile.c:155-216 computes, written through imm_dp_trans_idx /
+     * imm_dp_change_trans like there */
     float xt[DCP_NXTRANS];
     if (dcp_xtrans(seq_size, multi_hits, hmmer3_compat, xt)) return fail(RC_EINVAL, "sequence cannot be empty");
-    prof->seq_size = seq_size;
-    prof->multi_hits = multi_hits;
-    prof->hmmer3_compat = hmmer3_compat;
+    struct imm_dp *dp = &prof->null.dp;
+    unsigned const R = prof->null.R;
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, R, R), xt[DCP_HOST_X_RR]);
+    dp = &prof->alt.dp;
+    unsigned const S = prof->alt.S, N = prof->alt.N, B = prof->alt.B, E = prof->alt.E, J = prof->alt.J,
+                   C = prof->alt.C, T = prof->alt.T;
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, S, B), xt[DCP_HOST_X_SB]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, S, N), xt[DCP_HOST_X_SN]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, N, N), xt[DCP_HOST_X_NN]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, N, B), xt[DCP_HOST_X_NB]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, E, T), xt[DCP_HOST_X_ET]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, E, C), xt[DCP_HOST_X_EC]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, C, C), xt[DCP_HOST_X_CC]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, C, T), xt[DCP_HOST_X_CT]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, E, B), xt[DCP_HOST_X_EB]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, E, J), xt[DCP_HOST_X_EJ]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, J, J), xt[DCP_HOST_X_JJ]);
+    imm_dp_change_trans(dp, imm_dp_trans_idx(dp, J, B), xt[DCP_HOST_X_JB]);
     return RC_OK;
 }
 
-static enum rc adopt(struct protein_profile *p, dcp_profile *impl, int rc)
+/* take ownership of a freshly built compact profile and mirror it into the reference's members */
+enum rc dcp_host_adopt(struct protein_profile *p, dcp_profile *impl, int rc)
 {
     if (!impl) return fail((enum rc)rc, "failed to build the profile");
+    unsigned const M = dcp_profile_core_size(impl);
+    struct nuclt_dist *nd = realloc(p->alt.match_ndists, (size_t)M * sizeof *nd);
+    if (!nd)
+    {
+        dcp_profile_del(impl);
+        return fail(RC_ENOMEM, "alloc nuclt dists");
+    }
+    p->alt.match_ndists = nd;
     if (p->impl)
     {
-        if (g_ctx_db == p->impl) g_ctx_db = NULL;
+        dcp_host_forget_profile(p->impl);
         dcp_profile_del(p->impl);
     }
     p->impl = impl;
-    p->core_size = dcp_profile_core_size(impl);
-    p->seq_size = 0;
+    p->core_size = M;
+    memcpy(p->consensus, dcp_profile_consensus(impl), (size_t)M + 1);
+    ndist_from_row(&p->null.ndist, dcp_profile_null_dist(impl));
+    ndist_from_row(&p->alt.insert_ndist, dcp_profile_insert_dist(impl));
+    float const *md = dcp_profile_match_dist(impl);
+    for (unsigned k = 0; k < M; ++k)
+    {
+        nuclt_dist_init(nd + k, p->code->nuclt);
+        ndist_from_row(nd + k, md + (size_t)k * DCP_NDIST);
+    }
+    /* a fresh DP: specials back at LOG1 (protein_model.c:322-340) until protein_profile_setup */
+    for (int i = 0; i < DCP_NXTRANS; ++i)
+        p->xtrans[i] = IMM_LPROB_ONE;
     return RC_OK;
+}
+
+enum rc protein_profile_absorb(struct protein_profile *p, struct protein_model const *m)
+{
+    if (p->code->nuclt != protein_model_nuclt(m)) return fail(RC_EINVAL, "Different nucleotide alphabets.");
+    if (p->amino != protein_model_amino(m)) return fail(RC_EINVAL, "Different amino alphabets.");
+    if (!model_complete(m)) return fail(RC_EINVAL, "model is incomplete: %u of %u nodes, %u of %u transitions",
+                                        m->alt.node_idx == UINT_MAX ? 0 : m->alt.node_idx, m->core_size,
+                                        m->alt.trans_idx == UINT_MAX ? 0 : m->alt.trans_idx, m->core_size + 1);
+    int rc = 0;
+    dcp_profile *impl = dcp_profile_new(p->super.accession, m->core_size, (int)m->cfg.entry_dist, m->cfg.epsilon,
+                                        m->null.lprobs, &m->alt.match_lprobs[0][0], &m->alt.trans[0].data[0],
+                                        m->consensus, &rc);
+    return dcp_host_adopt(p, impl, rc);
 }
 
 enum rc protein_profile_sample(struct protein_profile *p, unsigned seed, unsigned core_size)
@@ -369,7 +640,7 @@ enum rc protein_profile_sample(struct protein_profile *p, unsigned seed, unsigne
     int rc = 0;
     dcp_profile *impl = dcp_profile_sample(p->super.accession, seed, core_size, (int)p->cfg.entry_dist,
                                            p->cfg.epsilon, &rc);
-    return adopt(p, impl, rc);
+    return dcp_host_adopt(p, impl, rc);
 }
 
 enum rc protein_profile_from_params(struct protein_profile *p, unsigned core_size, imm_float const *null_lprobs,
@@ -378,7 +649,7 @@ enum rc protein_profile_from_params(struct protein_profile *p, unsigned core_siz
     int rc = 0;
     dcp_profile *impl = dcp_profile_new(p->super.accession, core_size, (int)p->cfg.entry_dist, p->cfg.epsilon,
                                         null_lprobs, match_lprobs, trans, NULL, &rc);
-    return adopt(p, impl, rc);
+    return dcp_host_adopt(p, impl, rc);
 }
 
 enum rc protein_profile_decode(struct protein_profile const *prof, struct imm_seq const *seq, unsigned state_id,
@@ -389,8 +660,8 @@ enum rc protein_profile_decode(struct protein_profile const *prof, struct imm_se
     if (seq->size < 1 || seq->size > 5) return fail(RC_EINVAL, "failed to decode sequence");
     for (unsigned i = 0; i < seq->size; ++i)
     {
-        unsigned id = symbol_id(seq->abc, seq->str[i]);
-        if (id > 3) return fail(RC_EINVAL, "failed to decode sequence");
+        int const id = imm_abc_symbol_idx(seq->abc, seq->str[i]);
+        if (id < 0 || id > 3) return fail(RC_EINVAL, "failed to decode sequence");
         frag[i] = (uint8_t)id;
     }
     if (dcp_profile_decode(prof->impl, frag, seq->size, state_id, out))
@@ -400,324 +671,422 @@ enum rc protein_profile_decode(struct protein_profile const *prof, struct imm_se
     return RC_OK;
 }
 
-struct protein_codec protein_codec_init(struct protein_profile const *prof, struct imm_path const *path)
+void protein_profile_write_dot(struct protein_profile const *p, FILE *fp)
 {
-    return (struct protein_codec){0, 0, prof, path};
+    imm_dp_write_dot(&p->alt.dp, fp, protein_state_name);
 }
 
+/* ---- pack / unpack: the map(16) of src/model/protein_profile.c:38-117,338-400 ------------------------------
+ * Key order and value types are the reference's.  The two imm_dp values are imm's own serialisation
+ * there (its layout lives in the absent imm library); this library writes its own dp value
+ *     map(3) {"fmt": "dcp-dp-1", "xtrans": 1darray f32 [13 | 1], "trans8": 1darray f32 [8 * M | 0]}
+ * (alt: all 13 specials + the core transitions; null: RR alone) and on reading accepts exactly
+ * that.  A dp value in any other layout -- a file pressed by the reference -- is skipped as one
+ * MessagePack object, everything else of the profile is still parsed and validated, and the
+ * unpack ends with RC_EPARSE "transitions live in imm's dp serialisation: unsupported". */
+static char const kDpFormat[] = "dcp-dp-1";
+
+enum imm_rc imm_dp_pack(struct imm_dp const *dp, struct lip_file *file)
+{
+    struct protein_profile const *p = dp->owner;
+    if (!lip_write_map_size(file, 3)) return IMM_FAILURE;
+    if (!lip_write_cstr(file, "fmt") || !lip_write_cstr(file, kDpFormat)) return IMM_FAILURE;
+    bool const alt = p && !dp->null_model;
+    unsigned const nx = alt ? DCP_NXTRANS : (p ? 1u : 0u);
+    unsigned const nt = alt && p->impl ? 8u * p->core_size : 0u;
+    if (!lip_write_cstr(file, "xtrans") || !lip_write_1darray_size_type(file, nx, LIP_1DARRAY_F32)) return IMM_FAILURE;
+    if (nx && !lip_write_1darray_f32_data(file, nx, p->xtrans)) return IMM_FAILURE;
+    if (!lip_write_cstr(file, "trans8") || !lip_write_1darray_size_type(file, nt, LIP_1DARRAY_F32)) return IMM_FAILURE;
+    if (nt && !lip_write_1darray_f32_data(file, nt, dcp_profile_trans8(p->impl))) return IMM_FAILURE;
+    return IMM_OK;
+}
+
+struct dp_blob
+{
+    bool foreign;
+    unsigned nx, nt;
+    float xtrans[DCP_NXTRANS];
+    float *trans8;
+};
+
+static enum imm_rc dp_blob_read(struct dp_blob *b, struct lip_file *file)
+{
+    memset(b, 0, sizeof *b);
+    long const at = ftell(file->fp);
+    unsigned n = 0;
+    char fmt[16] = {0};
+    if (at >= 0 && lip_read_map_size(file, &n) && n == 3 && expect_map_key(file, "fmt") &&
+        lip_read_cstr(file, sizeof fmt, fmt) && !strcmp(fmt, kDpFormat))
+    {
+        enum lip_1darray_type ty;
+        if (!expect_map_key(file, "xtrans") || !lip_read_1darray_size_type(file, &b->nx, &ty) ||
+            ty != LIP_1DARRAY_F32 || b->nx > DCP_NXTRANS || !lip_read_1darray_f32_data(file, b->nx, b->xtrans))
+            return IMM_FAILURE;
+        if (!expect_map_key(file, "trans8") || !lip_read_1darray_size_type(file, &b->nt, &ty) ||
+            ty != LIP_1DARRAY_F32 || b->nt > 8u * PROTEIN_MODEL_CORE_SIZE_MAX)
+            return IMM_FAILURE;
+        if (b->nt)
+        {
+            b->trans8 = malloc((size_t)b->nt * sizeof(float));
+            if (!b->trans8 || !lip_read_1darray_f32_data(file, b->nt, b->trans8))
+            {
+                free(b->trans8);
+                b->trans8 = NULL;
+                return IMM_FAILURE;
+            }
+        }
+        return IMM_OK;
+    }
+    /* not this library's dp value: rewind and step over it as one opaque object */
+    if (at < 0 || fseek(file->fp, at, SEEK_SET)) return IMM_FAILURE;
+    file->error = false;
+    b->foreign = true;
+    return lip_skip_object(file) ? IMM_OK : IMM_FAILURE;
+}
+
+enum imm_rc imm_dp_unpack(struct imm_dp *dp, struct lip_file *file)
+{
+    /* stand-alone form (standard_profile_unpack): consume and check the value */
+    struct dp_blob b;
+    (void)dp;
+    enum imm_rc rc = dp_blob_read(&b, file);
+    free(b.trans8);
+    return rc;
+}
+
+static enum rc read_state_idx(struct lip_file *file, char const *key, unsigned *out)
+{
+    if (!expect_map_key(file, key)) return fail(RC_EIO, "skip key");
+    if (!lip_read_unsigned(file, out)) return fail(RC_EIO, "read %s state", key);
+    return RC_OK;
+}
+
+enum rc protein_profile_unpack(struct protein_profile *p, struct lip_file *file)
+{
+    struct profile *prof = &p->super;
+    unsigned size = 0;
+    if (!lip_read_map_size(file, &size)) return fail(RC_EIO, "read profile map size");
+    if (size != 16) return fail(RC_EPARSE, "profile map has %u keys, expected 16", size);
+
+    if (!expect_map_key(file, "accession")) return fail(RC_EIO, "read key");
+    if (!lip_read_cstr(file, PROFILE_ACC_SIZE, prof->accession)) return fail(RC_EIO, "read accession");
+
+    struct dp_blob nul, alt;
+    if (!expect_map_key(file, "null")) return fail(RC_EIO, "skip key");
+    if (dp_blob_read(&nul, file)) return fail(RC_EFAIL, "read null dp");
+    free(nul.trans8);
+    nul.trans8 = NULL;
+    if (!expect_map_key(file, "alt") || dp_blob_read(&alt, file))
+    {
+        return fail(file->error ? RC_EIO : RC_EFAIL, "read alt dp");
+    }
+    enum rc rc = RC_OK;
+    float *rows = NULL;
+    char consensus[PROTEIN_MODEL_CORE_SIZE_MAX + 1];
+
+    if (!expect_map_key(file, "core_size") || !lip_read_unsigned(file, &size))
+    {
+        rc = fail(RC_EIO, "read core size");
+        goto done;
+    }
+    if (size == 0 || size > PROTEIN_MODEL_CORE_SIZE_MAX)
+    {
+        rc = fail(RC_EIO, "profile is too long");
+        goto done;
+    }
+    unsigned const M = size;
+    if (!expect_map_key(file, "consensus") || !lip_read_cstr(file, sizeof consensus, consensus))
+    {
+        rc = fail(RC_EIO, "read consensus");
+        goto done;
+    }
+    unsigned st[8];
+    static char const *const keys[8] = {"R", "S", "N", "B", "E", "J", "C", "T"};
+    for (int i = 0; i < 8 && !rc; ++i)
+        rc = read_state_idx(file, keys[i], &st[i]);
+    if (rc) goto done;
+
+    rows = malloc(((size_t)M + 2) * DCP_NDIST * sizeof(float)); /* null, insert, match[M] */
+    if (!rows)
+    {
+        rc = fail(RC_ENOMEM, "alloc nuclt dists");
+        goto done;
+    }
+    struct nuclt_dist nd;
+    nuclt_dist_init(&nd, p->code->nuclt);
+    if (!expect_map_key(file, "null_ndist") || nuclt_dist_unpack(&nd, file))
+    {
+        rc = fail(RC_EIO, "read null_ndist");
+        goto done;
+    }
+    ndist_to_row(&nd, rows);
+    if (!expect_map_key(file, "alt_insert_ndist") || nuclt_dist_unpack(&nd, file))
+    {
+        rc = fail(RC_EIO, "read alt_insert_ndist");
+        goto done;
+    }
+    ndist_to_row(&nd, rows + DCP_NDIST);
+    if (!expect_map_key(file, "alt_match_ndist") || !lip_read_array_size(file, &size))
+    {
+        rc = fail(RC_EIO, "read size");
+        goto done;
+    }
+    if (size != M)
+    {
+        rc = fail(RC_EPARSE, "alt_match_ndist has %u entries for core_size %u", size, M);
+        goto done;
+    }
+    for (unsigned i = 0; i < M; ++i)
+    {
+        if (nuclt_dist_unpack(&nd, file))
+        {
+            rc = fail(RC_EIO, "read alt_match_ndist");
+            goto done;
+        }
+        ndist_to_row(&nd, rows + ((size_t)i + 2) * DCP_NDIST);
+    }
+
+    /* everything but the transitions is in hand; they are in the alt dp value */
+    if (alt.foreign || nul.foreign)
+    {
+        rc = fail(RC_EPARSE,
+                  "profile '%s' (core_size %u): its transitions live in imm's dp serialisation, which this "
+                  "library cannot read (framing, consensus and %u nuclt_dists parsed and valid)",
+                  prof->accession, M, M + 2);
+        goto done;
+    }
+    if (alt.nt != 8u * M || alt.nx != DCP_NXTRANS || nul.nx != 1)
+    {
+        rc = fail(RC_EPARSE, "dp value does not match core_size %u", M);
+        goto done;
+    }
+    int drc = 0;
+    dcp_profile *impl = dcp_profile_from_parts(prof->accession, M, (int)p->cfg.entry_dist, p->cfg.epsilon, consensus,
+                                               alt.trans8, rows, rows + DCP_NDIST, rows + 2 * DCP_NDIST, &drc);
+    rc = dcp_host_adopt(p, impl, drc);
+    if (rc) goto done;
+    p->null.R = st[0];
+    p->alt.S = st[1], p->alt.N = st[2], p->alt.B = st[3], p->alt.E = st[4], p->alt.J = st[5], p->alt.C = st[6],
+    p->alt.T = st[7];
+    /* the dp carries whatever specials it was packed with (LOG1 for a pressed DB) */
+    memcpy(p->xtrans, alt.xtrans, sizeof p->xtrans);
+    p->xtrans[DCP_HOST_X_RR] = nul.xtrans[0];
+
+done:
+    free(rows);
+    free(alt.trans8);
+    return rc;
+}
+
+enum rc protein_profile_pack(struct protein_profile const *prof, struct lip_file *file)
+{
+    if (!prof->impl) return fail(RC_EINVAL, "profile holds no model");
+    if (!lip_write_map_size(file, 16)) return fail(RC_EIO, "write profile map size");
+    if (!lip_write_cstr(file, "accession") || !lip_write_cstr(file, prof->super.accession))
+        return fail(RC_EIO, "write accession");
+    if (!lip_write_cstr(file, "null") || imm_dp_pack(&prof->null.dp, file)) return fail(RC_EFAIL, "write null dp");
+    if (!lip_write_cstr(file, "alt") || imm_dp_pack(&prof->alt.dp, file)) return fail(RC_EFAIL, "write alt dp");
+    if (!lip_write_cstr(file, "core_size") || !lip_write_int(file, prof->core_size)) return fail(RC_EIO, "write core_size");
+    if (!lip_write_cstr(file, "consensus") || !lip_write_cstr(file, prof->consensus)) return fail(RC_EIO, "write consensus");
+    unsigned const st[8] = {prof->null.R, prof->alt.S, prof->alt.N, prof->alt.B,
+                            prof->alt.E,  prof->alt.J, prof->alt.C, prof->alt.T};
+    static char const *const keys[8] = {"R", "S", "N", "B", "E", "J", "C", "T"};
+    for (int i = 0; i < 8; ++i)
+        if (!lip_write_cstr(file, keys[i]) || !lip_write_int(file, st[i])) return fail(RC_EIO, "write %s state", keys[i]);
+    enum rc rc;
+    if (!lip_write_cstr(file, "null_ndist")) return fail(RC_EIO, "write null_ndist key");
+    if ((rc = nuclt_dist_pack(&prof->null.ndist, file))) return rc;
+    if (!lip_write_cstr(file, "alt_insert_ndist")) return fail(RC_EIO, "write alt_insert_ndist key");
+    if ((rc = nuclt_dist_pack(&prof->alt.insert_ndist, file))) return rc;
+    if (!lip_write_cstr(file, "alt_match_ndist") || !lip_write_array_size(file, prof->core_size))
+        return fail(RC_EIO, "write array length");
+    for (unsigned i = 0; i < prof->core_size; ++i)
+        if ((rc = nuclt_dist_pack(prof->alt.match_ndists + i, file))) return rc;
+    return RC_OK;
+}
+
+/* ---- imm value serialisations the db code calls ------------------------------------------------------------
+ * imm_abc: map {"symbols": str, "any_symbol": uint, "typeid": uint}; the reader takes these keys from a
+ * map in any order and skips keys it does not know (imm's own layout carries more). */
+enum imm_rc imm_abc_pack(struct imm_abc const *abc, struct lip_file *file)
+{
+    bool ok = lip_write_map_size(file, 3) && lip_write_cstr(file, "symbols") && lip_write_cstr(file, abc->symbols) &&
+              lip_write_cstr(file, "any_symbol") && lip_write_uint(file, (unsigned char)abc->any_symbol) &&
+              lip_write_cstr(file, "typeid") && lip_write_uint(file, (uint64_t)abc->vtable.typeid);
+    return ok ? IMM_OK : IMM_FAILURE;
+}
+
+enum imm_rc imm_abc_unpack(struct imm_abc *abc, struct lip_file *file)
+{
+    unsigned n = 0;
+    if (!lip_read_map_size(file, &n)) return IMM_FAILURE;
+    bool have_symbols = false;
+    abc->any_symbol = 'X';
+    abc->vtable.typeid = IMM_ABC;
+    abc->vtable.derived = NULL;
+    for (unsigned i = 0; i < n; ++i)
+    {
+        char key[32] = {0};
+        if (!lip_read_cstr(file, sizeof key, key)) return IMM_FAILURE;
+        if (!strcmp(key, "symbols"))
+        {
+            if (!lip_read_cstr(file, sizeof abc->symbols, abc->symbols)) return IMM_FAILURE;
+            have_symbols = true;
+        }
+        else if (!strcmp(key, "any_symbol"))
+        {
+            unsigned v = 0;
+            if (!lip_read_unsigned(file, &v) || v == 0 || v > 127) return IMM_FAILURE;
+            abc->any_symbol = (char)v;
+        }
+        else if (!strcmp(key, "typeid"))
+        {
+            unsigned v = 0;
+            if (!lip_read_unsigned(file, &v) || v > IMM_RNA) return IMM_FAILURE;
+            abc->vtable.typeid = (enum imm_abc_typeid)v;
+        }
+        else if (!lip_skip_object(file))
+            return IMM_FAILURE;
+    }
+    if (!have_symbols) return IMM_FAILURE;
+    abc->size = (unsigned)strlen(abc->symbols);
+    abc->any_symbol_id = abc->size;
+    return abc->size ? IMM_OK : IMM_FAILURE;
+}
+
+enum imm_rc imm_nuclt_lprob_pack(struct imm_nuclt_lprob const *nucltp, struct lip_file *file)
+{
+    return lip_write_1darray_size_type(file, IMM_NUCLT_SIZE, LIP_1DARRAY_F32) &&
+                   lip_write_1darray_f32_data(file, IMM_NUCLT_SIZE, nucltp->lprobs)
+               ? IMM_OK
+               : IMM_FAILURE;
+}
+
+static enum imm_rc read_f32_block(struct lip_file *file, unsigned want, float *out)
+{
+    unsigned n = 0;
+    enum lip_1darray_type ty;
+    if (!lip_read_1darray_size_type(file, &n, &ty) || ty != LIP_1DARRAY_F32 || n != want) return IMM_FAILURE;
+    if (!lip_read_1darray_f32_data(file, n, out)) return IMM_FAILURE;
+    for (unsigned i = 0; i < n; ++i)
+        if (isnan(out[i])) return IMM_FAILURE;
+    return IMM_OK;
+}
+
+enum imm_rc imm_nuclt_lprob_unpack(struct imm_nuclt_lprob *nucltp, struct lip_file *file)
+{
+    return read_f32_block(file, IMM_NUCLT_SIZE, nucltp->lprobs);
+}
+
+enum imm_rc imm_codon_marg_pack(struct imm_codon_marg const *codonm, struct lip_file *file)
+{
+    unsigned const n = sizeof codonm->lprobs / sizeof(imm_float);
+    return lip_write_1darray_size_type(file, n, LIP_1DARRAY_F32) &&
+                   lip_write_1darray_f32_data(file, n, &codonm->lprobs[0][0][0])
+               ? IMM_OK
+               : IMM_FAILURE;
+}
+
+enum imm_rc imm_codon_marg_unpack(struct imm_codon_marg *codonm, struct lip_file *file)
+{
+    return read_f32_block(file, sizeof codonm->lprobs / sizeof(imm_float), &codonm->lprobs[0][0][0]);
+}
+
+/* ---- standard_profile: typed shell (src/model/standard_profile.c, standard_state.c:5-10) ------------------ */
+static void standard_del(struct profile *prof) { (void)prof; }
+static struct imm_dp const *standard_null_dp(struct profile const *prof)
+{
+    return &((struct standard_profile const *)prof)->dp.null;
+}
+static struct imm_dp const *standard_alt_dp(struct profile const *prof)
+{
+    return &((struct standard_profile const *)prof)->dp.alt;
+}
+static enum rc standard_unpack(struct profile *prof, struct lip_file *file)
+{
+    return standard_profile_unpack((struct standard_profile *)prof, file);
+}
+unsigned standard_state_name(unsigned id, char name[IMM_STATE_NAME_SIZE])
+{
+    assert(id <= UINT16_MAX);
+    return (unsigned)snprintf(name, IMM_STATE_NAME_SIZE, "S%u", id);
+}
+void standard_profile_init(struct standard_profile *p, char const *accession, struct imm_code const *code)
+{
+    struct profile_vtable const vtable = {PROFILE_STANDARD, standard_del, standard_unpack, standard_null_dp,
+                                          standard_alt_dp};
+    profile_init(&p->super, accession, code, vtable, standard_state_name);
+    imm_dp_init(&p->dp.null, code);
+    imm_dp_init(&p->dp.alt, code);
+    p->dp.null.null_model = 1;
+}
+enum rc standard_profile_pack(struct standard_profile const *prof, struct lip_file *file)
+{
+    if (!lip_write_map_size(file, 2)) return fail(RC_EIO, "write map size");
+    if (!lip_write_cstr(file, "null") || imm_dp_pack(&prof->dp.null, file)) return fail(RC_EFAIL, "write null dp");
+    if (!lip_write_cstr(file, "alt") || imm_dp_pack(&prof->dp.alt, file)) return fail(RC_EFAIL, "write alt dp");
+    return RC_OK;
+}
+enum rc standard_profile_unpack(struct standard_profile *prof, struct lip_file *file)
+{
+    if (!expect_map_size(file, 2)) return fail(RC_EIO, "read map size");
+    if (!expect_map_key(file, "null") || imm_dp_unpack(&prof->dp.null, file)) return fail(RC_EFAIL, "read null dp");
+    if (!expect_map_key(file, "alt") || imm_dp_unpack(&prof->dp.alt, file)) return fail(RC_EFAIL, "read alt dp");
+    return RC_OK;
+}
+
+/* ---- protein_codec (src/model/protein_codec.c) ---------------------------------------------------------------- */
 enum rc protein_codec_next(struct protein_codec *codec, struct imm_seq const *seq, struct imm_codon *codon)
 {
-    struct imm_step const *step = NULL;
-    while (codec->idx < imm_path_nsteps(codec->path))
-    {
-        step = imm_path_step(codec->path, codec->idx);
-        if (!protein_state_is_mute(step->state_id)) break;
+    /* advance to the next emitting step; mute steps (S, B, D_k, E, T) carry no fragment */
+    unsigned const n = imm_path_nsteps(codec->path);
+    while (codec->idx < n && protein_state_is_mute(imm_path_step(codec->path, codec->idx)->state_id))
         codec->idx++;
-    }
-    if (codec->idx >= imm_path_nsteps(codec->path)) return RC_END;
+    if (codec->idx >= n) return RC_END;
+    struct imm_step const *step = imm_path_step(codec->path, codec->idx++);
     if (codec->start + step->seqlen > imm_seq_size(seq)) return fail(RC_EINVAL, "path does not fit the sequence");
     struct imm_seq frag = imm_subseq(seq, codec->start, step->seqlen);
     codec->start += step->seqlen;
-    codec->idx++;
     return protein_profile_decode(codec->prof, &frag, step->state_id, codon);
 }
 
-/* ---- profile_reader: count-balanced contiguous partitions (profile_reader.c:54-72) ----------------- */
-enum rc profile_reader_setup(struct profile_reader *reader, struct protein_db const *db, unsigned npartitions)
+/* ---- protein_h3reader (src/model/protein_h3reader.c:18-72) over dcp_h3reader_* ------------------------------------ */
+void protein_h3reader_init(struct protein_h3reader *reader, struct imm_amino const *amino,
+                           struct imm_nuclt_code const *code, struct protein_cfg cfg, FILE *fp)
 {
-    if (npartitions == 0) return fail(RC_EINVAL, "can't have zero partitions");
-    if (npartitions > NUM_THREADS) return fail(RC_EINVAL, "too many partitions");
-    memset(reader, 0, sizeof *reader);
-    reader->db = db;
-    unsigned sizes[DCP_NUM_THREADS];
-    reader->npartitions = dcp_partition_by_count(db->nprofiles, npartitions, sizes);
-    for (unsigned i = 0; i < reader->npartitions; ++i)
-    {
-        reader->partition_size[i] = sizes[i];
-        reader->partition_begin[i + 1] = reader->partition_begin[i] + sizes[i];
-    }
-    return profile_reader_rewind_all(reader);
+    reader->impl = dcp_h3reader_open_fp(fp, (int)cfg.entry_dist, cfg.epsilon);
+    dcp_swissprot_null_lprobs(reader->null_lprobs); /* protein_h3reader.c:79-103 */
+    protein_model_init(&reader->model, amino, code, cfg, reader->null_lprobs);
+    reader->name[0] = reader->acc[0] = '\0';
 }
 
-unsigned profile_reader_npartitions(struct profile_reader const *reader) { return reader->npartitions; }
-unsigned profile_reader_partition_size(struct profile_reader const *reader, unsigned partition)
+enum rc protein_h3reader_next(struct protein_h3reader *reader)
 {
-    return reader->partition_size[partition];
-}
-unsigned profile_reader_nprofiles(struct profile_reader const *reader)
-{
-    unsigned n = 0;
-    for (unsigned i = 0; i < reader->npartitions; ++i)
-        n += reader->partition_size[i];
-    return n;
-}
-enum rc profile_reader_rewind_all(struct profile_reader *reader)
-{
-    for (unsigned i = 0; i < reader->npartitions; ++i)
-        reader->cursor[i] = reader->partition_begin[i];
-    return RC_OK;
-}
-enum rc profile_reader_rewind(struct profile_reader *reader, unsigned partition)
-{
-    reader->cursor[partition] = reader->partition_begin[partition];
-    return RC_OK;
-}
-enum rc profile_reader_next(struct profile_reader *reader, unsigned partition, struct profile **profile)
-{
-    if (reader->cursor[partition] == reader->partition_begin[partition + 1]) return RC_END;
-    *profile = &reader->db->profiles[reader->cursor[partition]++]->super; /* borrowed */
-    return RC_OK;
-}
-
-/* ---- scan thread ------------------------------------------------------------------------------------ */
-void thread_init(struct scan_thread *t, unsigned id, struct profile_reader *reader, bool multi_hits,
-                 bool hmmer3_compat, double lrt_threshold)
-{
-    memset(t, 0, sizeof *t);
-    t->id = id;
-    t->reader = reader;
-    t->multi_hits = multi_hits;
-    t->hmmer3_compat = hmmer3_compat;
-    t->lrt_threshold = lrt_threshold;
-}
-
-void thread_setup_job(struct scan_thread *t, enum imm_abc_typeid abc_typeid, enum profile_typeid typeid,
-                      int64_t scan_id)
-{
-    snprintf(t->prod.abc_name, sizeof t->prod.abc_name, "%s", imm_abc_typeid_name(abc_typeid));
-    snprintf(t->prod.profile_typeid, sizeof t->prod.profile_typeid, "%s", profile_typeid_name(typeid));
-    snprintf(t->prod.version, sizeof t->prod.version, "%s", "0.1.0");
-    t->prod.scan_id = scan_id;
-}
-
-void thread_setup_seq(struct scan_thread *t, struct imm_seq *seq, int64_t seq_id)
-{
-    t->seq = seq;
-    t->prod.seq_id = seq_id;
-}
-
-void thread_cleanup(struct scan_thread *t)
-{
-    if (t->gpu) dcp_gpu_ctx_del(t->gpu);
-    free(t->rows);
-    t->gpu = NULL;
-    t->rows = NULL;
-    t->rows_len = t->rows_cap = 0;
-    t->db_resident = false;
-}
-
-static enum rc rows_reserve(struct scan_thread *t, size_t extra)
-{
-    if (t->rows_len + extra + 1 <= t->rows_cap) return RC_OK;
-    size_t cap = t->rows_cap ? t->rows_cap * 2 : 4096;
-    while (cap < t->rows_len + extra + 1)
-        cap *= 2;
-    char *p = realloc(t->rows, cap);
-    if (!p) return fail(RC_ENOMEM, "alloc product rows");
-    t->rows = p;
-    t->rows_cap = cap;
-    return RC_OK;
-}
-
-static enum rc thread_prepare(struct scan_thread *t, int tid)
-{
-    struct profile_reader *reader = t->reader;
-    unsigned const n = reader->partition_size[t->id];
-    if (!t->gpu)
-    {
-        int ndev = dcp_gpu_device_count();
-        if (ndev <= 0) return fail(RC_EFAIL, "no HIP device: thread_run has no CPU implementation here");
-        t->gpu = dcp_gpu_ctx_new(tid % ndev);
-        if (!t->gpu) return fail(RC_EFAIL, "failed to create the device context");
-    }
-    /* the partition's profiles are uploaded once and stay resident between sequences
-     * (the reference re-reads and re-unpacks them for every sequence: scan_thread.c:96-99) */
-    if (!t->db_resident)
-    {
-        dcp_profile **impls = malloc((size_t)n * sizeof *impls);
-        if (!impls) return fail(RC_ENOMEM, "alloc");
-        enum rc rc = profile_reader_rewind(reader, t->id);
-        struct profile *prof = NULL;
-        unsigned i = 0;
-        while (!rc && (rc = profile_reader_next(reader, t->id, &prof)) == RC_OK)
-            impls[i++] = ((struct protein_profile *)prof)->impl;
-        if (rc == RC_END) rc = RC_OK;
-        if (!rc && dcp_gpu_db_upload(t->gpu, impls, n, 0)) rc = fail(RC_EFAIL, "%s", dcp_gpu_last_error(t->gpu));
-        free(impls);
-        if (rc) return rc;
-        t->db_resident = true;
-    }
-    return RC_OK;
-}
-
-enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
-                         unsigned nseqs)
-{
-    struct profile_reader *reader = t->reader;
-    if (!reader || !seqs || nseqs == 0) return fail(RC_EINVAL, "thread has no reader or sequence");
-    unsigned const first = reader->partition_begin[t->id];
-    unsigned const n = reader->partition_size[t->id];
-    if (n == 0) return RC_OK;
-    enum rc rc = thread_prepare(t, tid);
+    if (!reader->impl) return fail(RC_EFAIL, "reader is not open");
+    struct dcp_h3params prm;
+    int drc = dcp_h3reader_next_params(reader->impl, &prm);
+    if (drc == DCP_END) return RC_END;
+    if (drc == DCP_EINVAL) return fail(RC_EINVAL, "%s", dcp_h3reader_error(reader->impl));
+    if (drc) return fail(RC_EFAIL, "%s", dcp_h3reader_error(reader->impl));
+    enum rc rc = protein_model_setup(&reader->model, prm.core_size);
     if (rc) return rc;
-
-    /* protein_profile_setup(pp, size, ...) for every profile rejects the empty sequence (:112) */
-    size_t total = 0;
-    for (unsigned q = 0; q < nseqs; ++q)
+    struct protein_trans t;
+    memcpy(t.data, prm.trans, sizeof t.data);
+    if ((rc = protein_model_add_trans(&reader->model, t))) return rc;
+    for (unsigned k = 0; k < prm.core_size; ++k)
     {
-        if (seqs[q].size == 0) return fail(RC_EINVAL, "sequence cannot be empty");
-        total += seqs[q].size;
+        if ((rc = protein_model_add_node(&reader->model, prm.match_lprobs + 20 * (size_t)k, prm.consensus[k])))
+            return rc;
+        memcpy(t.data, prm.trans + 7 * ((size_t)k + 1), sizeof t.data);
+        if ((rc = protein_model_add_trans(&reader->model, t))) return rc;
     }
-    /* the caller's buffers may be overwritten by the next fetch (scan.c:227-229): copy now */
-    char *text = malloc(total + 1);
-    uint32_t *off = malloc(((size_t)nseqs + 1) * sizeof *off);
-    if (!text || !off)
-    {
-        free(text), free(off);
-        return fail(RC_ENOMEM, "alloc sequence batch");
-    }
-    off[0] = 0;
-    for (unsigned q = 0; q < nseqs; ++q)
-    {
-        memcpy(text + off[q], seqs[q].str, seqs[q].size);
-        off[q + 1] = off[q] + seqs[q].size;
-    }
-    int drc = dcp_gpu_seqs_upload_text(t->gpu, text, off, nseqs);
-    if (drc) rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
-    struct dcp_scan_params prm = {t->multi_hits, t->hmmer3_compat, (float)t->lrt_threshold, 0, 0};
-    if (!rc && ((drc = dcp_gpu_scan(t->gpu, &prm)) || (drc = dcp_gpu_sync(t->gpu))))
-        rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
-
-    /* lrt filter ran on the device (scan_thread.c:121-123): only hits come back, sorted by (seq, profile) */
-    unsigned nhits = 0;
-    size_t hit_cap = (size_t)n * nseqs;
-    struct dcp_hit *hits = NULL;
-    struct dcp_step *steps = NULL;
-    uint32_t *soff = NULL;
-    uint8_t *ids = NULL;
-    if (!rc)
-    {
-        drc = dcp_gpu_fetch_hits(t->gpu, NULL, 0, &nhits); /* count first */
-        if (drc && drc != DCP_ENOMEM) rc = fail((enum rc)drc, "fetch hits");
-        if (!rc && nhits > hit_cap) rc = fail(RC_EFAIL, "more hits than pairs");
-    }
-    if (!rc && nhits)
-    {
-        hits = malloc((size_t)nhits * sizeof *hits);
-        if (!hits) rc = fail(RC_ENOMEM, "alloc hits");
-        if (!rc && (drc = dcp_gpu_fetch_hits(t->gpu, hits, nhits, &nhits))) rc = fail((enum rc)drc, "fetch hits");
-        size_t cap = 0;
-        for (unsigned h = 0; !rc && h < nhits; ++h)
-            cap += 2 * (size_t)seqs[hits[h].seq_idx].size +
-                   2 * (size_t)reader->db->profiles[first + hits[h].profile_idx]->core_size + 16;
-        if (!rc)
-        {
-            steps = malloc(cap * sizeof *steps);
-            soff = malloc(((size_t)nhits + 1) * sizeof *soff);
-            ids = malloc(total);
-            if (!steps || !soff || !ids) rc = fail(RC_ENOMEM, "alloc paths");
-        }
-        if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, hits, nhits, t->multi_hits, t->hmmer3_compat, 0, steps,
-                                              (unsigned)cap, soff, NULL)))
-            rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
-        for (size_t i = 0; !rc && i < total; ++i)
-            ids[i] = (uint8_t)symbol_id(seqs[0].abc, text[i]);
-        for (unsigned h = 0; !rc && h < nhits; ++h)
-        {
-            unsigned const q = hits[h].seq_idx;
-            struct protein_profile const *pp = reader->db->profiles[first + hits[h].profile_idx];
-            /* strcpy(t->prod.profile_name, prof->accession); match_setup; write_product (:125-128) */
-            snprintf(t->prod.profile_name, sizeof t->prod.profile_name, "%s", pp->super.accession);
-            t->prod.seq_id = seq_ids ? seq_ids[q] : t->prod.seq_id;
-            t->prod.null_loglik = (double)hits[h].null_loglik;
-            t->prod.alt_loglik = (double)hits[h].alt_loglik;
-            unsigned ns = soff[h + 1] - soff[h];
-            size_t need = 512 + 64 * ((size_t)ns + 1) + 2 * (size_t)seqs[q].size;
-            if ((rc = rows_reserve(t, need))) break;
-            long w = dcp_prod_format_row(t->rows + t->rows_len, t->rows_cap - t->rows_len, t->prod.scan_id,
-                                         t->prod.seq_id, t->prod.profile_name, t->prod.abc_name, t->prod.alt_loglik,
-                                         t->prod.null_loglik, t->prod.profile_typeid, t->prod.version, pp->impl,
-                                         ids + off[q], seqs[q].size, steps + soff[h], ns);
-            if (w < 0)
-            {
-                rc = fail(RC_EIO, "failed to write prod");
-                break;
-            }
-            t->rows_len += (size_t)w;
-            t->nprods++;
-        }
-    }
-    free(ids);
-    free(soff);
-    free(steps);
-    free(hits);
-    free(off);
-    free(text);
-    return rc;
+    snprintf(reader->name, sizeof reader->name, "%s", prm.name);
+    snprintf(reader->acc, sizeof reader->acc, "%s", prm.acc);
+    return RC_OK;
 }
 
-enum rc thread_run(struct scan_thread *t, int tid)
+void protein_h3reader_del(struct protein_h3reader const *reader)
 {
-    if (!t->reader || !t->seq) return fail(RC_EINVAL, "thread has no reader or sequence");
-    int64_t id = t->prod.seq_id;
-    return thread_run_batch(t, tid, t->seq, &id, 1);
+    if (reader->impl) dcp_h3reader_close(reader->impl);
+    protein_model_del(&reader->model);
 }
-
-enum rc scan_run_local(struct protein_db const *db, struct scan_seq const *seqs, unsigned nseqs,
-                       unsigned num_threads, bool multi_hits, bool hmmer3_compat, double lrt_threshold,
-                       int64_t scan_id, unsigned batch, FILE *prods)
-{
-    if (!db || !seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
-    struct profile_reader reader;
-    enum rc rc = profile_reader_setup(&reader, db, num_threads); /* prepare_readers: scan.c:45-74 */
-    if (rc) return rc;
-    unsigned const nparts = profile_reader_npartitions(&reader);
-    struct scan_thread *th = calloc(nparts, sizeof *th);
-    struct imm_seq *bseq = malloc((size_t)batch * sizeof *bseq);
-    int64_t *bid = malloc((size_t)batch * sizeof *bid);
-    if (!th || !bseq || !bid)
-    {
-        free(th), free(bseq), free(bid);
-        return fail(RC_ENOMEM, "alloc scan");
-    }
-    for (unsigned i = 0; i < nparts; ++i)
-    {
-        thread_init(&th[i], i, &reader, multi_hits, hmmer3_compat, lrt_threshold);
-        thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, scan_id);
-    }
-    for (unsigned b0 = 0; b0 < nseqs && !rc; b0 += batch)
-    {
-        unsigned const nb = nseqs - b0 < batch ? nseqs - b0 : batch;
-        for (unsigned q = 0; q < nb; ++q)
-        {
-            bseq[q] = imm_seq(imm_str(seqs[b0 + q].data), &imm_dna_iupac.super);
-            bid[q] = seqs[b0 + q].id;
-        }
-        enum rc shared = RC_OK;
-#pragma omp parallel for schedule(static, 1)
-        for (unsigned i = 0; i < nparts; ++i)
-        {
-            enum rc r = thread_run_batch(&th[i], (int)i, bseq, bid, nb);
-            if (r)
-            {
-#pragma omp atomic write
-                shared = r; /* scan.c:246-248: first failing partition fails the scan */
-            }
-        }
-        rc = shared;
-    }
-    if (!rc)
-    {
-        /* prod_fclose: header, then every thread's rows in thread order (prod.c:119-134) */
-        if (fputs(prod_header(), prods) < 0) rc = fail(RC_EIO, "fail to finish product");
-        for (unsigned i = 0; !rc && i < nparts; ++i)
-            if (th[i].rows_len && fwrite(th[i].rows, 1, th[i].rows_len, prods) != th[i].rows_len)
-                rc = fail(RC_EIO, "fail to finish product");
-    }
-    for (unsigned i = 0; i < nparts; ++i)
-        thread_cleanup(&th[i]);
-    free(th), free(bseq), free(bid);
-    return rc;
-}
-
-char const *prod_header(void) { return dcp_prod_header(); }

@@ -33,6 +33,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -98,8 +99,22 @@ dcp_profile *dcp_profile_new(char const *accession, unsigned core_size,
 dcp_profile *dcp_profile_sample(char const *accession, unsigned seed,
                                 unsigned core_size, int entry_dist,
                                 float epsilon, int *rc);
+/* A profile from its scan-time parts (what a pressed DB stores: protein_profile.c:338-400):
+ * trans8 [8][core_size] rows entry(B->Mk), MM, IM, DM, MD, DD (edges INTO node k), MI, II;
+ * null / insert dists [129], match dists [core_size][129] (4 base lprobs + 5x5x5 codon marginals).
+ * NULL + DCP_EINVAL for core_size outside 1..4096, epsilon outside [0,1] or a NaN value. */
+dcp_profile *dcp_profile_from_parts(char const *accession, unsigned core_size, int entry_dist, float epsilon,
+                                    char const *consensus, float const *trans8, float const *null_dist,
+                                    float const *insert_dist, float const *match_dist, int *rc);
 void dcp_profile_del(dcp_profile *);
 unsigned dcp_profile_core_size(dcp_profile const *);
+int dcp_profile_entry_dist(dcp_profile const *);
+float dcp_profile_epsilon(dcp_profile const *);
+/* imm_rnd(seed) / its next double in [0,1) (xoshiro256+ seeded by splitmix64: pinned by the
+ * reference's golden test/protein_profile.c:41), and imm_lprob_normalize. */
+void dcp_rnd_seed(uint64_t state[4], uint64_t seed);
+double dcp_rnd_next(uint64_t state[4]);
+void dcp_lprob_normalize(unsigned n, float *lprobs);
 char const *dcp_profile_accession(dcp_profile const *);
 
 /* ---- HMMER3 ASCII reader: .hmm -> profiles, what protein_h3reader_next +
@@ -113,6 +128,21 @@ char const *dcp_profile_accession(dcp_profile const *);
  * there is none. */
 typedef struct dcp_h3reader dcp_h3reader;
 dcp_h3reader *dcp_h3reader_open(char const *path, int entry_dist, float epsilon);
+/* Same over a stream the caller keeps owning (protein_h3reader_init takes a FILE*). */
+dcp_h3reader *dcp_h3reader_open_fp(FILE *fp, int entry_dist, float epsilon);
+/* The next profile's raw parameters instead of a built profile (what protein_h3reader_next leaves in
+ * its protein_model): match_lprobs [core_size][20], trans [core_size+1][7]; pointers stay valid
+ * until the next call on this reader. Same return codes as dcp_h3reader_next. */
+struct dcp_h3params
+{
+    unsigned core_size;
+    float const *match_lprobs;
+    float const *trans;
+    char const *consensus;
+    char const *name;
+    char const *acc;
+};
+int dcp_h3reader_next_params(dcp_h3reader *, struct dcp_h3params *out);
 /* DCP_OK and *out (caller owns it), DCP_END at end of file, DCP_EPARSE on malformed input
  * (message in dcp_h3reader_error), DCP_EINVAL for core sizes outside 1..4096. */
 int dcp_h3reader_next(dcp_h3reader *, dcp_profile **out);
@@ -217,6 +247,13 @@ int dcp_gpu_seqs_upload(dcp_gpu_ctx *, uint8_t const *seqs,
 int dcp_gpu_seqs_upload_text(dcp_gpu_ctx *, char const *text,
                              uint32_t const *seq_off, unsigned nseqs);
 unsigned dcp_gpu_nseqs(dcp_gpu_ctx const *);
+/* Explicit special transitions for the resident sequences: xt [nseqs][13] in dcp_xtrans order.
+ * By default a scan derives them from each sequence's length and the scan's flags (what
+ * protein_profile_setup does per pair); imm_dp_viterbi on a profile whose transitions were set some
+ * other way -- or never: the LOG1 defaults of protein_model.c:322-340, as test/protein_db.c:73 runs
+ * it -- passes them here.  They stay in force until the next sequence upload; the scan flags
+ * multi_hits / hmmer3_compat are then ignored.  NaN values are rejected (DCP_EINVAL). */
+int dcp_gpu_seqs_set_xtrans(dcp_gpu_ctx *, float const *xt, unsigned nseqs);
 
 struct dcp_scan_params
 {
@@ -341,6 +378,44 @@ long dcp_prod_format_row(char *buf, size_t cap, int64_t scan_id, int64_t seq_id,
                          struct dcp_step const *steps, unsigned nsteps);
 /* The header line prod_fclose writes (src/server/prod.c:119-121). */
 char const *dcp_prod_header(void);
+
+/* ------------------------------------------------------------------------ */
+/* One process per GPU: profile shards + the hit gather over RCCL */
+/* ------------------------------------------------------------------------ */
+/* Pairs (profile, query) are independent: every rank keeps a contiguous profile shard (balanced by sum
+ * of core sizes = DP cells) resident and scans ALL queries against it; the only exchange of the path
+ * is the gather of the 16-byte hit records.  librccl.so is loaded on first use. */
+typedef struct dcp_dist dcp_dist;
+enum { DCP_DIST_ID_BYTES = 128 }; /* NCCL_UNIQUE_ID_BYTES */
+/* Rank 0 creates the communicator id (ncclGetUniqueId) and hands it to the other ranks through
+ * whatever channel the launcher has (bench.py: torch.distributed; a C launcher: the file variant). */
+int dcp_dist_unique_id(unsigned char id[DCP_DIST_ID_BYTES]);
+dcp_dist *dcp_dist_init(unsigned char const id[DCP_DIST_ID_BYTES], int rank, int nranks, int device);
+/* Rendezvous through a file: rank 0 writes the id to `path`, the others wait up to timeout_s for it. */
+dcp_dist *dcp_dist_init_from_file(char const *path, int rank, int nranks, int device, double timeout_s);
+void dcp_dist_free(dcp_dist *);
+int dcp_dist_rank(dcp_dist const *);
+int dcp_dist_nranks(dcp_dist const *);
+char const *dcp_dist_last_error(dcp_dist const *);
+/* [begin, end) of rank's shard: dcp_partition_by_cells over nranks. */
+void dcp_dist_shard(unsigned const *core_sizes, unsigned nprofiles, int nranks, int rank, unsigned *begin,
+                    unsigned *end);
+/* Gather the hit records of every rank's last scan.  hits_dev / nhits_dev: the device buffer and counter
+ * the scan wrote (dcp_gpu_set_hit_buffer); profile_offset: first global profile index of this rank's
+ * shard (records carry shard-local indices); scan_stream: dcp_gpu_stream(ctx) (synchronised first).
+ * Counts + offsets travel in one 2-word all-gather, the records in one grouped ncclSend/ncclRecv
+ * (gather-v).  root >= 0: only that rank receives; root < 0: every rank does.  On a receiving rank
+ * *out is a malloc'ed array (dcp_dist_free_hits) of *nout records with GLOBAL profile indices,
+ * ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total. */
+int dcp_dist_gather_hits(dcp_dist *, void const *hits_dev, void const *nhits_dev, unsigned cap,
+                         unsigned profile_offset, int root, void *scan_stream, struct dcp_hit **out,
+                         unsigned *nout);
+void dcp_dist_free_hits(struct dcp_hit *hits);
+/* The bookkeeping of the gather alone (host, no device, no RCCL): counts[r] records of rank r lie back
+ * to back in `records`; out receives them with profile_idx += profile_offset[r], ordered by
+ * (seq_idx, profile_idx).  Returns the total, -1 if cap is too small. */
+long dcp_dist_merge_hits(unsigned const *counts, unsigned const *profile_offset, int nranks,
+                         struct dcp_hit const *records, struct dcp_hit *out, unsigned cap);
 
 /* Work accounting of the last scan (or of a full scan if none ran yet):
  * alt-model DP cells = sum over pairs of core_size * L (the Gcell/s numerator)

@@ -702,6 +702,11 @@ struct profile_reader
     unsigned partition_first[NUM_THREADS + 1];
 };
 enum rc profile_reader_setup(struct profile_reader *reader, struct db_reader *db, unsigned npartitions);
+/* Same, but the contiguous partitions are balanced by profile BYTES (proportional to core size, i.e.
+ * to DP cells) instead of by profile count: one partition per GPU wants equal work, and the
+ * reference's count balance is a known imbalance for mixed sizes.  Offsets and sizes
+ * obey the same invariants as profile_reader_setup's. */
+enum rc profile_reader_setup_balanced(struct profile_reader *reader, struct db_reader *db, unsigned npartitions);
 unsigned profile_reader_npartitions(struct profile_reader const *reader);
 unsigned profile_reader_partition_size(struct profile_reader const *reader, unsigned partition);
 unsigned profile_reader_nprofiles(struct profile_reader const *reader);
@@ -799,8 +804,8 @@ struct scan_thread
     /* device side: the partition's profiles are unpacked once and stay resident between sequences */
     dcp_gpu_ctx *gpu;
     bool db_resident;
-    struct protein_profile *resident; /* [partition_size]: host objects for decode / product rows */
-    unsigned nresident;
+    dcp_profile **impls; /* [nimpls]: the partition's compact profiles (decode / product rows) */
+    unsigned nimpls;
 };
 void thread_init(struct scan_thread *t, unsigned id, struct profile_reader *reader, bool multi_hits,
                  bool hmmer3_compat, double lrt_threshold, prod_fwrite_match_func_t write_match_func);
@@ -836,8 +841,9 @@ struct scan_cfg
     int64_t scan_id;
     bool multi_hits;
     bool hmmer3_compat;
-    double lrt_threshold; /* scan.c:221 passes 10.0 */
-    unsigned batch;
+    double lrt_threshold;  /* scan.c:221 passes 10.0 */
+    unsigned batch;        /* sequences per device pass; 0 = 1 */
+    bool balance_by_cells; /* partitions by profile bytes (one per GPU) instead of by count */
 };
 enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned num_threads,
                         scan_next_seq_func_t next_seq, void *arg);

@@ -4,8 +4,9 @@
  * Part 1 follows what the reference checks in test/protein_profile.c (sampled M=2
  * profile, eps 0.1, 32-nt query): setup(0) is RC_EINVAL; null loglik, path length and
  * end steps; alt loglik for both entry distributions, path ends, decoded codons.
- * Part 2 drives profile_reader + thread_run over a small resident DB with a planted
- * domain and checks the product rows.
+ * Part 2 presses a small database into a .dcp file (protein_db_writer), reads it back
+ * (protein_db_reader, profile_reader) and drives thread_run / scan_run_local over it with a planted
+ * domain, checking the product rows.
  *
  * Expected values are the reference's goldens (float32 tolerance 5e-5 relative,
  * test/hope_support.h:26).  Exit status = number of failed checks.
@@ -14,6 +15,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static int failed;
 #define CHECK(cond)                                                            \
@@ -32,7 +34,7 @@ static char const *const want_codons[10] = {"ATG", "AAA", "CGC", "ATA", "GCA", "
 
 static void golden_profile(enum entry_dist entry, double want_alt)
 {
-    struct imm_nuclt const *nuclt = &imm_dna_iupac;
+    struct imm_nuclt const *nuclt = imm_super(&imm_dna_iupac);
     struct imm_nuclt_code code;
     imm_nuclt_code_init(&code, nuclt);
     struct protein_profile prof;
@@ -95,14 +97,52 @@ static void golden_profile(enum entry_dist entry, double want_alt)
     CHECK(rc == RC_END);
     CHECK(i == 10);
 
-    /* a sequence whose length disagrees with the last setup is refused, not mis-scored */
+    /* imm keeps whatever transitions the last protein_profile_setup wrote: a shorter sequence is scored
+     * with the 32-nt transitions (not refused), and differs from the score after a matching setup */
     struct imm_seq shorter = imm_subseq(&seq, 0, 10);
     CHECK(imm_task_setup(task, &shorter) == IMM_OK);
-    CHECK(imm_dp_viterbi(dp, task, &prod) != IMM_OK);
+    CHECK(imm_dp_viterbi(dp, task, &prod) == IMM_OK);
+    imm_float const stale = prod.loglik;
+    CHECK(isfinite(stale));
+    CHECK(protein_profile_setup(&prof, 10, true, false) == RC_OK);
+    CHECK(imm_dp_viterbi(dp, task, &prod) == IMM_OK);
+    CHECK(isfinite(prod.loglik) && prod.loglik != stale);
+
+    /* a profile that never saw protein_profile_setup runs with the LOG1 = 0 defaults
+     * (protein_model.c:322-340; test/protein_db.c:73 does exactly this): scores are finite and at
+     * least as high as with any real (<= 0) special transitions */
+    struct protein_profile fresh;
+    protein_profile_init(&fresh, "fresh", &imm_amino_iupac, &code, protein_cfg(entry, 0.1f));
+    CHECK(protein_profile_sample(&fresh, 1, 2) == RC_OK);
+    CHECK(imm_task_reset(task, &fresh.alt.dp) == IMM_OK);
+    CHECK(imm_task_setup(task, &seq) == IMM_OK);
+    CHECK(imm_dp_viterbi(&fresh.alt.dp, task, &prod) == IMM_OK);
+    CHECK(isfinite(prod.loglik) && prod.loglik > (imm_float)want_alt);
+    CHECK(imm_path_step(&prod.path, 0)->state_id == PROTEIN_S_STATE);
+    profile_del(&fresh.super);
+
+    /* RNA sequences are scored over their own alphabet; the any-symbol is rejected */
+    struct imm_nuclt_code rcode;
+    imm_nuclt_code_init(&rcode, imm_super(&imm_rna_iupac));
+    struct protein_profile rprof;
+    protein_profile_init(&rprof, "rna", &imm_amino_iupac, &rcode, protein_cfg(entry, 0.1f));
+    CHECK(protein_profile_sample(&rprof, 1, 2) == RC_OK);
+    char rna[sizeof query];
+    for (size_t c = 0; c < sizeof query; ++c)
+        rna[c] = query[c] == 'T' ? 'U' : query[c];
+    struct imm_seq rseq = imm_seq(imm_str(rna), rprof.super.code->abc);
+    CHECK(protein_profile_setup(&rprof, imm_seq_size(&rseq), true, false) == RC_OK);
+    CHECK(imm_task_reset(task, &rprof.alt.dp) == IMM_OK && imm_task_setup(task, &rseq) == IMM_OK);
+    CHECK(imm_dp_viterbi(&rprof.alt.dp, task, &prod) == IMM_OK);
+    NEAR(prod.loglik, want_alt);
+    struct imm_seq xseq = imm_seq(imm_str("ACGUXACGU"), rprof.super.code->abc);
+    CHECK(imm_task_setup(task, &xseq) == IMM_OK);
+    CHECK(imm_dp_viterbi(&rprof.alt.dp, task, &prod) != IMM_OK);
+    profile_del(&rprof.super);
 
     profile_del(&prof.super);
-    imm_prod_del(&prod);
-    imm_task_del(task);
+    imm_del(&prod);
+    imm_del(task);
 }
 
 /* A profile whose node k strongly prefers Met (ATG) or Trp (TGG): both have one codon only. */
@@ -135,72 +175,161 @@ static void peaked_profile(struct protein_profile *prof, struct imm_nuclt_code c
     free(trans);
 }
 
-static void scan_threads(void)
+/* press `n` peaked profiles into a .dcp file the way hmm_press does: protein_db_writer_open,
+ * protein_db_writer_pack_profile per profile, db_writer_close (test/protein_db.c:18-50) */
+enum { NPROF = 5 };
+static unsigned const kSizes[NPROF] = {20, 33, 41, 57, 60};
+static char g_domain[NPROF][3 * 60 + 1];
+static char g_db_path[64];
+
+static void press_db(void)
 {
+    struct imm_nuclt const *nuclt = imm_super(&imm_dna_iupac);
     struct imm_nuclt_code code;
-    imm_nuclt_code_init(&code, &imm_dna_iupac);
-    enum { NPROF = 5 };
-    struct protein_profile profs[NPROF], *ptrs[NPROF];
-    char domain[NPROF][3 * 60 + 1];
-    unsigned const sizes[NPROF] = {20, 33, 41, 57, 60};
+    imm_nuclt_code_init(&code, nuclt);
+    snprintf(g_db_path, sizeof g_db_path, "/tmp/dcp_test_db_XXXXXX");
+    int fd = mkstemp(g_db_path);
+    CHECK(fd >= 0);
+    FILE *fp = fdopen(fd, "wb");
+    CHECK(fp != NULL);
+    struct protein_db_writer db = {0};
+    CHECK(protein_db_writer_open(&db, fp, &imm_amino_iupac, nuclt, PROTEIN_CFG_DEFAULT) == RC_OK);
     for (unsigned p = 0; p < NPROF; ++p)
     {
+        struct protein_profile prof;
         char acc[16];
         snprintf(acc, sizeof acc, "PF%05u", p);
-        peaked_profile(&profs[p], &code, acc, sizes[p], p, domain[p]);
-        ptrs[p] = &profs[p];
+        peaked_profile(&prof, &code, acc, kSizes[p], p, g_domain[p]);
+        CHECK(protein_db_writer_pack_profile(&db, &prof) == RC_OK);
+        profile_del(&prof.super);
     }
-    struct protein_db db = {NPROF, ptrs};
-    struct profile_reader reader;
-    CHECK(profile_reader_setup(&reader, &db, 0) == RC_EINVAL);
-    CHECK(profile_reader_setup(&reader, &db, NUM_THREADS + 1) == RC_EINVAL);
-    CHECK(profile_reader_setup(&reader, &db, 2) == RC_OK);
+    /* a profile pressed with another cfg does not belong in this database */
+    struct protein_profile odd;
+    protein_profile_init(&odd, "odd", &imm_amino_iupac, &code, protein_cfg(ENTRY_DIST_UNIFORM, 0.01f));
+    CHECK(protein_profile_sample(&odd, 3, 4) == RC_OK);
+    CHECK(protein_db_writer_pack_profile(&db, &odd) == RC_EINVAL);
+    profile_del(&odd.super);
+    CHECK(db_writer_close((struct db_writer *)&db, true) == RC_OK);
+    CHECK(fclose(fp) == 0);
+}
+
+static char *slurp(FILE *fp)
+{
+    fflush(fp);
+    fseek(fp, 0, SEEK_END);
+    long len = ftell(fp);
+    rewind(fp);
+    char *text = calloc((size_t)len + 1, 1);
+    CHECK(fread(text, 1, (size_t)len, fp) == (size_t)len);
+    return text;
+}
+
+static unsigned g_custom_steps;
+static enum rc count_match_func(FILE *fp, void const *match)
+{
+    struct match const *m = match;
+    g_custom_steps++;
+    return fprintf(fp, "%u", (unsigned)m->step->seqlen) < 0 ? RC_EIO : RC_OK;
+}
+
+static void scan_threads(void)
+{
+    FILE *fp = fopen(g_db_path, "rb");
+    CHECK(fp != NULL);
+    struct protein_db_reader db = {0};
+    CHECK(protein_db_reader_open(&db, fp) == RC_OK);
+    CHECK(db.super.nprofiles == NPROF);
+    CHECK(db.super.profile_typeid == PROFILE_PROTEIN);
+    CHECK(imm_abc_typeid(imm_super(&db.nuclt)) == IMM_DNA);
+    CHECK(imm_abc_typeid(imm_super(&db.amino)) == IMM_AMINO);
+    CHECK(db.cfg.entry_dist == ENTRY_DIST_OCCUPANCY && db.cfg.epsilon == 0.01f);
+
+    static struct profile_reader reader; /* 64 profiles inside: not for the stack */
+    CHECK(profile_reader_setup(&reader, (struct db_reader *)&db, 0) == RC_EINVAL);
+    CHECK(profile_reader_setup(&reader, (struct db_reader *)&db, NUM_THREADS + 1) == RC_EINVAL);
+    CHECK(profile_reader_setup(&reader, (struct db_reader *)&db, 2) == RC_OK);
     CHECK(profile_reader_npartitions(&reader) == 2);
     CHECK(profile_reader_partition_size(&reader, 0) == 3 && profile_reader_partition_size(&reader, 1) == 2);
     CHECK(profile_reader_nprofiles(&reader) == NPROF);
+    /* byte offsets: partition i+1 starts where partition i's profile_sizes end */
+    CHECK(reader.partition_offset[1] - reader.partition_offset[0] ==
+          (int64_t)db.super.profile_sizes[0] + db.super.profile_sizes[1] + db.super.profile_sizes[2]);
     struct profile *it = NULL;
     unsigned seen = 0;
     while (profile_reader_next(&reader, 1, &it) == RC_OK)
     {
         CHECK(profile_typeid(it) == PROFILE_PROTEIN);
-        CHECK(it == &profs[3 + seen].super);
+        CHECK(it == (struct profile *)&reader.profiles[1]); /* borrowed, reused */
+        char acc[16];
+        snprintf(acc, sizeof acc, "PF%05u", 3 + seen);
+        CHECK(strcmp(it->accession, acc) == 0);
+        CHECK(((struct protein_profile *)it)->core_size == kSizes[3 + seen]);
         seen++;
     }
     CHECK(seen == 2);
     CHECK(profile_reader_next(&reader, 1, &it) == RC_END);
+    CHECK(profile_reader_end(&reader, 1));
+
+    /* an unpacked profile scores without protein_profile_setup, as test/protein_db.c:66-80 does */
+    CHECK(profile_reader_rewind(&reader, 0) == RC_OK);
+    CHECK(profile_reader_next(&reader, 0, &it) == RC_OK);
+    {
+        struct imm_prod prod = imm_prod();
+        struct imm_task *task = imm_task_new(profile_alt_dp(it));
+        struct imm_seq seq = imm_seq(imm_str(g_domain[0]), imm_super(&db.nuclt));
+        CHECK(imm_task_setup(task, &seq) == IMM_OK);
+        CHECK(imm_dp_viterbi(profile_alt_dp(it), task, &prod) == IMM_OK);
+        CHECK(isfinite(prod.loglik));
+        imm_del(task);
+        imm_del(&prod);
+    }
 
     /* query 0 carries profile 3's domain between random-looking flanks; query 1 is flank only */
     char q0[512], q1[] = "ACGTTGCAAGGCTTAACCGGTTACGATCGATTAGC";
-    snprintf(q0, sizeof q0, "ACGTTGCAAGGCTTAACC%sGGTTACGATCGATTAGC", domain[3]);
+    snprintf(q0, sizeof q0, "ACGTTGCAAGGCTTAACC%sGGTTACGATCGATTAGC", g_domain[3]);
     struct scan_thread th[2];
+    CHECK(prod_fopen(2) == RC_OK);
     for (unsigned i = 0; i < 2; ++i)
     {
-        thread_init(&th[i], i, &reader, true, false, 10.0);
+        thread_init(&th[i], i, &reader, true, false, 10.0, protein_match_write_func);
         thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, 77);
     }
     char const *queries[2] = {q0, q1};
     for (int64_t s = 0; s < 2; ++s)
     {
-        struct imm_seq seq = imm_seq(imm_str(queries[s]), &imm_dna_iupac.super);
+        struct imm_seq seq = imm_seq(imm_str(queries[s]), imm_super(&db.nuclt));
         for (unsigned i = 0; i < 2; ++i)
         {
             thread_setup_seq(&th[i], &seq, 100 + s);
             CHECK(thread_run(&th[i], (int)i) == RC_OK);
         }
     }
+    /* an empty sequence is RC_EINVAL, as protein_profile_setup reports it */
+    struct imm_seq empty = imm_seq(imm_str(""), imm_super(&db.nuclt));
+    thread_setup_seq(&th[0], &empty, 102);
+    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
+    /* a symbol outside the alphabet is rejected too */
+    struct imm_seq bad = imm_seq(imm_str("ACGTNACGT"), imm_super(&db.nuclt));
+    thread_setup_seq(&th[0], &bad, 103);
+    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
+
+    /* prod_fclose: header + thread 0's rows + thread 1's rows */
+    CHECK(prod_fclose() == RC_OK);
+    CHECK(prod_final_fp() != NULL && prod_final_path()[0] == '/');
+    char *text = slurp(prod_final_fp());
+    CHECK(strncmp(text, prod_header(), strlen(prod_header())) == 0);
+    CHECK(strncmp(prod_header(), "scan_id\tseq_id\tprofile_name", 27) == 0);
+    char *rows = text + strlen(prod_header());
     /* profile 3 lives in partition 1 and must be the hit for query 0; the flank-only query hits nothing */
-    CHECK(th[1].nprods >= 1);
-    CHECK(th[1].rows && strstr(th[1].rows, "77\t100\tPF00003\tdna\t") == th[1].rows);
-    if (th[1].rows)
+    char *hit = strstr(rows, "77\t100\tPF00003\tdna\t");
+    CHECK(hit != NULL);
+    if (hit)
     {
-        CHECK(strstr(th[1].rows, "\tprotein\t0.1.0\t,S,,;") != NULL);
-        CHECK(strstr(th[1].rows, ";,T,,\n") != NULL);
-        CHECK(strstr(th[1].rows, "ATG,M") != NULL && strstr(th[1].rows, ",ATG,M") != NULL);
-        CHECK(strstr(th[1].rows, "\t101\t") == NULL); /* nothing reported for the second query */
+        CHECK(strstr(hit, "\tprotein\t" DECIPHON_VERSION "\t,S,,;") != NULL);
+        CHECK(strstr(hit, ";,T,,\n") != NULL);
+        CHECK(strstr(hit, "ATG,M") != NULL && strstr(hit, ",ATG,M") != NULL);
         /* the fragments of the match column tile the query */
-        size_t rl = strlen(th[1].rows);
-        char *row = malloc(rl + 1);
-        memcpy(row, th[1].rows, rl + 1);
+        char *row = strdup(hit);
         char *nl = strchr(row, '\n');
         if (nl) *nl = '\0';
         char *match = strrchr(row, '\t');
@@ -210,20 +339,38 @@ static void scan_threads(void)
         CHECK(strcmp(rebuilt, q0) == 0);
         free(row);
     }
-    if (th[0].rows) CHECK(strstr(th[0].rows, "\t101\t") == NULL);
-    /* an empty sequence is RC_EINVAL, as protein_profile_setup reports it */
-    struct imm_seq empty = imm_seq(imm_str(""), &imm_dna_iupac.super);
-    thread_setup_seq(&th[0], &empty, 102);
-    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
-    /* a symbol outside the alphabet is rejected too */
-    struct imm_seq bad = imm_seq(imm_str("ACGTNACGT"), &imm_dna_iupac.super);
-    thread_setup_seq(&th[0], &bad, 103);
-    CHECK(thread_run(&th[0], 0) == RC_EINVAL);
-    CHECK(strncmp(prod_header(), "scan_id\tseq_id\tprofile_name", 27) == 0);
+    CHECK(strstr(rows, "\t101\t") == NULL); /* nothing reported for the second query */
+    free(text);
+    prod_final_cleanup();
+
+    /* the caller's write_match_func is what writes the match column: one call per path step */
+    struct scan_thread custom;
+    thread_init(&custom, 1, &reader, true, false, 10.0, count_match_func);
+    thread_setup_job(&custom, IMM_DNA, PROFILE_PROTEIN, 78);
+    struct imm_seq seq0 = imm_seq(imm_str(q0), imm_super(&db.nuclt));
+    thread_setup_seq(&custom, &seq0, 200);
+    g_custom_steps = 0;
+    CHECK(thread_run(&custom, 1) == RC_OK);
+    CHECK(prod_fclose() == RC_OK);
+    text = slurp(prod_final_fp());
+    hit = strstr(text, "78\t200\tPF00003\t");
+    CHECK(hit != NULL && g_custom_steps > 10);
+    if (hit)
+    {
+        unsigned seps = 0;
+        for (char *c = strrchr(hit, '\t'); c && *c && *c != '\n'; ++c)
+            seps += *c == ';';
+        CHECK(seps + 1 == g_custom_steps);
+    }
+    free(text);
+    prod_final_cleanup();
+    thread_cleanup(&custom);
+
     for (unsigned i = 0; i < 2; ++i)
         thread_cleanup(&th[i]);
-    for (unsigned p = 0; p < NPROF; ++p)
-        profile_del(&profs[p].super);
+    profile_reader_del(&reader);
+    db_reader_close((struct db_reader *)&db);
+    fclose(fp);
 }
 
 /* scan_run_local (batched dispatch, 2 partitions) must write the rows per-sequence thread_run writes */
@@ -240,63 +387,51 @@ static unsigned split_lines(char *text, char **lines, unsigned cap)
 
 static void scan_run_batched(void)
 {
-    struct imm_nuclt_code code;
-    imm_nuclt_code_init(&code, &imm_dna_iupac);
-    enum { NPROF = 5, NSEQ = 7 };
-    struct protein_profile profs[NPROF], *ptrs[NPROF];
-    char domain[NPROF][3 * 60 + 1];
-    unsigned const sizes[NPROF] = {20, 33, 41, 57, 60};
-    for (unsigned p = 0; p < NPROF; ++p)
-    {
-        char acc[16];
-        snprintf(acc, sizeof acc, "PF%05u", p);
-        peaked_profile(&profs[p], &code, acc, sizes[p], p, domain[p]);
-        ptrs[p] = &profs[p];
-    }
-    struct protein_db db = {NPROF, ptrs};
+    enum { NSEQ = 7 };
     char text[NSEQ][512];
     char const *flank[NSEQ] = {"ACGTTGCAAGGCTTAACC", "TTGACCA", "GGGCATCATCAGGAC", "A", "CCGTA", "GATTACAGATTACA", "TGCATGCAAT"};
     struct scan_seq seqs[NSEQ];
     for (unsigned q = 0; q < NSEQ; ++q)
     {
-        char const *dom = q == 0 ? domain[3] : q == 5 ? domain[1] : q == 6 ? domain[4] : "";
+        char const *dom = q == 0 ? g_domain[3] : q == 5 ? g_domain[1] : q == 6 ? g_domain[4] : "";
         snprintf(text[q], sizeof text[q], "%s%s%s", flank[q], dom, flank[(q + 3) % NSEQ]);
         seqs[q] = (struct scan_seq){1000 + q, text[q]};
     }
-    FILE *fp = tmpfile();
-    CHECK(fp != NULL);
-    CHECK(scan_run_local(&db, seqs, NSEQ, 2, true, false, 10.0, 9, 3, fp) == RC_OK);
-    long len = ftell(fp);
-    rewind(fp);
-    char *got = calloc((size_t)len + 1, 1);
-    CHECK(fread(got, 1, (size_t)len, fp) == (size_t)len);
-    fclose(fp);
+    FILE *out = tmpfile();
+    CHECK(out != NULL);
+    CHECK(scan_run_local(g_db_path, seqs, NSEQ, 2, true, false, 10.0, 9, 3, out) == RC_OK);
+    char *got = slurp(out);
+    fclose(out);
     CHECK(strncmp(got, prod_header(), strlen(prod_header())) == 0);
 
-    /* reference flow: one sequence at a time through thread_run, per partition */
-    struct profile_reader reader;
-    CHECK(profile_reader_setup(&reader, &db, 2) == RC_OK);
+    /* reference flow: one sequence at a time through thread_run, per (count-balanced) partition */
+    FILE *fp = fopen(g_db_path, "rb");
+    struct protein_db_reader db = {0};
+    CHECK(protein_db_reader_open(&db, fp) == RC_OK);
+    static struct profile_reader reader;
+    CHECK(profile_reader_setup(&reader, (struct db_reader *)&db, 2) == RC_OK);
     struct scan_thread th[2];
+    CHECK(prod_fopen(2) == RC_OK);
     for (unsigned i = 0; i < 2; ++i)
     {
-        thread_init(&th[i], i, &reader, true, false, 10.0);
+        thread_init(&th[i], i, &reader, true, false, 10.0, protein_match_write_func);
         thread_setup_job(&th[i], IMM_DNA, PROFILE_PROTEIN, 9);
     }
     for (unsigned q = 0; q < NSEQ; ++q)
     {
-        struct imm_seq seq = imm_seq(imm_str(text[q]), &imm_dna_iupac.super);
+        struct imm_seq seq = imm_seq(imm_str(text[q]), imm_super(&db.nuclt));
         for (unsigned i = 0; i < 2; ++i)
         {
             thread_setup_seq(&th[i], &seq, seqs[q].id);
             CHECK(thread_run(&th[i], (int)i) == RC_OK);
         }
     }
-    size_t wl = th[0].rows_len + th[1].rows_len;
-    char *want = calloc(wl + 1, 1);
-    if (th[0].rows) memcpy(want, th[0].rows, th[0].rows_len);
-    if (th[1].rows) memcpy(want + th[0].rows_len, th[1].rows, th[1].rows_len);
+    CHECK(prod_fclose() == RC_OK);
+    char *want = slurp(prod_final_fp());
+    prod_final_cleanup();
     char *gl[64], *wlines[64];
-    unsigned ng = split_lines(got + strlen(prod_header()), gl, 64), nw = split_lines(want, wlines, 64);
+    unsigned ng = split_lines(got + strlen(prod_header()), gl, 64);
+    unsigned nw = split_lines(want + strlen(prod_header()), wlines, 64);
     CHECK(ng == nw && ng >= 3);
     for (unsigned i = 0; i < ng && i < nw; ++i)
         CHECK(strcmp(gl[i], wlines[i]) == 0);
@@ -307,26 +442,31 @@ static void scan_run_batched(void)
     CHECK(found == 3);
     /* error propagation: an empty sequence fails the whole scan with RC_EINVAL */
     struct scan_seq bad[2] = {{1, "ACGTACGTACGT"}, {2, ""}};
-    fp = tmpfile();
-    CHECK(scan_run_local(&db, bad, 2, 2, true, false, 10.0, 9, 2, fp) == RC_EINVAL);
-    fclose(fp);
+    out = tmpfile();
+    CHECK(scan_run_local(g_db_path, bad, 2, 2, true, false, 10.0, 9, 2, out) == RC_EINVAL);
+    fclose(out);
+    /* a missing database is RC_EIO (scan.c:47-52) */
+    out = tmpfile();
+    CHECK(scan_run_local("/nonexistent/db.dcp", seqs, NSEQ, 2, true, false, 10.0, 9, 3, out) == RC_EIO);
+    fclose(out);
     free(got);
     free(want);
     for (unsigned i = 0; i < 2; ++i)
         thread_cleanup(&th[i]);
-    for (unsigned p = 0; p < NPROF; ++p)
-        profile_del(&profs[p].super);
+    profile_reader_del(&reader);
+    db_reader_close((struct db_reader *)&db);
+    fclose(fp);
 }
 
 /* test/standard_profile.c:5-31 is a smoke test (no numeric golden): a standard profile is a typed
  * shell around two imm_dp, and the scan path never takes one (profile_reader.c:95-98) */
 static void standard_profile_shell(void)
 {
-    struct imm_nuclt const *nuclt = &imm_dna_iupac;
+    struct imm_nuclt const *nuclt = imm_super(&imm_dna_iupac);
     struct imm_nuclt_code code;
     imm_nuclt_code_init(&code, nuclt);
     struct standard_profile prof;
-    standard_profile_init(&prof, "accession", &code);
+    standard_profile_init(&prof, "accession", &code.super);
     CHECK(profile_typeid(&prof.super) == PROFILE_STANDARD);
     CHECK(strcmp(profile_typeid_name(PROFILE_STANDARD), "standard") == 0);
     CHECK(strcmp(prof.super.accession, "accession") == 0);
@@ -352,8 +492,10 @@ int main(void)
     standard_profile_shell();
     golden_profile(ENTRY_DIST_UNIFORM, -55.59428153448);
     golden_profile(ENTRY_DIST_OCCUPANCY, -54.35543421312);
+    press_db();
     scan_threads();
     scan_run_batched();
+    remove(g_db_path);
     CHECK(xmath_partition_size(20000, 8, 7) == 2500);
     CHECK(fabsf(xmath_lrt(-48.927f, -54.355f) - (-10.856f)) < 1e-3f);
     if (failed) fprintf(stderr, "%d check(s) failed\n", failed);

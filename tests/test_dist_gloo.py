@@ -64,6 +64,13 @@ def _worker(rank, world, port, tmpdir):
             assert got.dtype == dcp.HIT_DTYPE and len(got) == sum(counts)
             assert np.array_equal(got, want)
             assert (got["profile_idx"] < len(sizes)).all()
+        # the C bookkeeping on its own: counts -> displacements -> global indices -> (seq, profile) order
+        a, c = local_hits(0, 6), local_hits(1, 0)
+        merged = ddist.merge_hits([6, 0, 0], [bounds[0][0], 17, 99], np.concatenate([a, c]))
+        exp = a.copy()
+        exp["profile_idx"] += bounds[0][0]
+        assert np.array_equal(merged, exp[np.lexsort((exp["profile_idx"], exp["seq_idx"]))])
+        assert len(ddist.merge_hits([0, 0], [0, 5], np.zeros(0, dcp.HIT_DTYPE))) == 0
         # overflow is an error, not silent truncation
         try:
             ddist.gather_hits(torch.zeros((4, 4), dtype=torch.int32), torch.tensor([9], dtype=torch.int32), b)
@@ -132,6 +139,50 @@ def _gpu_worker(rank, world, port, tmpdir):
         open(os.path.join(tmpdir, f"gpu_ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_c_rccl_gather_one_rank(dcp):
+    """The C host's RCCL path on real hardware, as far as one GPU allows: librccl.so is loaded on first
+    use, ncclCommInitRank(1 rank), the 2-word all-gather, the local-copy leg of the gather-v, the merge.
+    (RCCL refuses two ranks on one device; the N>1 exchange itself runs only on the driver's 8-GPU node.)"""
+    import ctypes as C
+    from deciphon_old_amd import dist as ddist
+    import test_gpu_parity as tp
+    from oracle_py import Oracle
+
+    rng = np.random.default_rng(11)
+    sizes = [int(m) for m in rng.integers(20, 120, 12)]
+    params = [tp.pfam_like_params(rng, M) for M in sizes]
+    cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+    orc = Oracle(32)
+    seqs = tp.rand_seqs(rng, 40, 30, 200)
+    for q, p in ((3, 2), (17, 9)):
+        seqs[q] = tp.planted_query(rng, orc.new(*params[p], 2, 0.01), sizes[p], flank=10)
+    sc = dcp.Scanner(0)
+    comm = ddist.CDist.create(ddist.CDist.unique_id(), 0, 1, 0)
+    try:
+        sc.upload_db([dcp.ProteinProfile.from_params(*prm, cfg) for prm in params])
+        sc.upload_seqs(seqs)
+        sc.scan(True, False, 10.0)
+        want = sc.hits()
+        assert len(want) >= 2
+        import torch
+        cap = 1024
+        hits_dev = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        count_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        sc.set_hit_buffer(hits_dev.data_ptr(), cap, count_dev.data_ptr())
+        sc.scan(True, False, 10.0, sync=False)
+        for root in (-1, 0):
+            got, total = comm.gather_hits(hits_dev.data_ptr(), count_dev.data_ptr(), cap, 0, sc.stream, root=root)
+            assert total == len(want) and np.array_equal(got, want)
+        # a shard that does not start at profile 0: indices come back global
+        got, _ = comm.gather_hits(hits_dev.data_ptr(), count_dev.data_ptr(), cap, 1000, sc.stream)
+        assert np.array_equal(got["profile_idx"], want["profile_idx"] + 1000)
+        sc.set_hit_buffer(None, 0, None)
+    finally:
+        comm.close()
+        sc.close()
 
 
 @pytest.mark.gpu

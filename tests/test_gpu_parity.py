@@ -246,6 +246,55 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
     assert a_multi > a_uni
 
 
+def test_explicit_special_transitions(dcp, oracle32, scanner, kern):
+    """imm_dp_viterbi scores with the special transitions the profile holds NOW, whatever they are
+    (dcp_gpu_seqs_set_xtrans): the LOG1 = 0 defaults of a profile that never saw
+    protein_profile_setup (protein_model.c:322-340; test/protein_db.c:73 runs exactly that), a setup
+    of another length, uni-hit values although the scan flag says multi-hit, arbitrary values.
+    Bit-exact against the oracle's recursion fed the same 13 numbers."""
+    rng = np.random.default_rng(91)
+    profiles = make_profiles(dcp, [(301, 2, ENTRY_DIST_OCCUPANCY, 0.01), (302, 77, ENTRY_DIST_OCCUPANCY, 0.01),
+                                   (303, 300, ENTRY_DIST_UNIFORM, 0.05)])
+    seqs = rand_seqs(rng, 7, 20, 260)
+    xt = np.zeros((len(seqs), 13), np.float32)            # row 0: never set up
+    xt[1] = dcp.xtrans(5000, True, False)                  # stale: some other length
+    xt[2] = dcp.xtrans(len(seqs[2]), False, False)         # uni-hit numbers
+    xt[3] = dcp.xtrans(len(seqs[3]), True, True)           # hmmer3_compat
+    xt[4] = -rng.random(13).astype(np.float32) * 3         # arbitrary finite
+    xt[5] = dcp.xtrans(len(seqs[5]), True, False)
+    xt[5, 9] = 0.0                                         # E -> B for free: every pair re-enters the core
+    xt[6] = dcp.xtrans(len(seqs[6]), True, False)
+    xt[6, 4] = -np.inf                                     # N -> B closed: only S -> B at row 0 enters
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.set_xtrans(xt)
+    for multi_flag in (True, False):  # the flags are ignored once explicit transitions are in force
+        scanner.scan(multi_flag, False, 10.0, kernel=kern)
+        gn, ga = scanner.scores()
+        for p, prof in enumerate(profiles):
+            em = scanner.match_table(p)
+            eps = prof_eps[id(prof)]
+            ei = dcp.frame_table_host(prof.insert_dist, eps)
+            en = dcp.frame_table_host(prof.null_dist, eps)
+            for q, sq in enumerate(seqs):
+                rc, a, b = oracle32.dp_tables(prof.trans8, em, ei, en, xt[q], bytes(sq))
+                assert rc == 0
+                assert same_bits(gn[q, p], a) and same_bits(ga[q, p], b), (q, p, gn[q, p], a, ga[q, p], b)
+    # a new upload returns to length-derived transitions
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0, kernel=kern)
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    gn, ga = scanner.scores()
+    assert same_bits(gn, on) and same_bits(ga, oa)
+    # NaN is refused, a wrong count too
+    bad = xt.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(dcp.DcpError):
+        scanner.set_xtrans(bad)
+    with pytest.raises(dcp.DcpError):
+        scanner.set_xtrans(xt[:3])
+
+
 def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner):
     """More feedback pairs than a redo list holds: the scan is repeated by the row-sweep kernel
     and stays bit-exact (the test-only setter shrinks the lists to one pair per size class)."""
