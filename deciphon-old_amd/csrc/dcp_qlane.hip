@@ -235,7 +235,11 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
                                        float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned &off, LaneXt const &xt,
-                                       bool live, bool at_end, bool &dirty, SweepOut &o)
+                                       bool live, bool at_end, bool &dirty, SweepOut &o
+#if DCP_QLANE_DIAG & 4
+                                       , unsigned &off2, unsigned din
+#endif
+                                       )
 {
     constexpr int KT = 4 * G;
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;
@@ -338,7 +342,11 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     if constexpr (!FIRST)
     {
         asm volatile("" : "+v"(off) : "v"(E));
+#if DCP_QLANE_DIAG & 4
+        ring_fetch_x<FIRST>(ring, (PH + D) % 5, pXm + din, pXd + din, pEm + din, off);
+#else
         ring_fetch_x<FIRST>(ring, (PH + D) % 5, pXm + D * NT, pXd + D * NT, pEm + D * NT, off);
+#endif
     }
 
     // `in` is consumed: refill it for row j+1 while the other groups compute
@@ -366,9 +374,14 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     if constexpr (!LAST)
     {
         // edges into the next tile's first node
-        st_off(pXm, off, mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]));
-        st_off(pXd, off, fmaxf(pm + tr.md[KT], pd + tr.dd[KT]));
-        st_off(pEm, off, E);
+#if DCP_QLANE_DIAG & 4
+        unsigned const offw = off2;
+#else
+        unsigned const offw = off;
+#endif
+        st_off(pXm, offw, mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]));
+        st_off(pXd, offw, fmaxf(pm + tr.md[KT], pd + tr.dd[KT]));
+        st_off(pEm, offw, E);
     }
     else
     {
@@ -394,11 +407,24 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
                                          uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
-                                         SweepOut &o)
+                                         SweepOut &o
+#if DCP_QLANE_DIAG & 4
+                                         , unsigned tile_odd
+#endif
+                                         )
 {
     constexpr int KT = 4 * G;
     constexpr unsigned wmask = kWMask;
+#if DCP_QLANE_DIAG & 4
+    // timing build: what a 2-stage tile pipeline would save -- the even -> odd tile boundary goes through
+    // ONE plane row (stays in L2, like an LDS ring would keep it on chip), the odd -> even one through HBM
+    unsigned const rowstep = tile_odd ? 0u : (unsigned)NT;      // input side of this tile
+    unsigned const rowstep_out = tile_odd ? (unsigned)NT : 0u;  // output side
+    unsigned const din = (unsigned)D * rowstep;
+    unsigned off2 = tid * 4u;
+#else
     constexpr unsigned rowstep = (DCP_QLANE_DIAG & 2) ? 0u : (unsigned)NT;
+#endif
     float const ni = ninf();
     TileTrans<G> tr;
     load_tile_trans<G>(tr, tt);
@@ -455,18 +481,26 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
 #pragma unroll
     for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
-        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)(r * NT * 4));
+        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * rowstep * 4u);
 
+#if DCP_QLANE_DIAG & 4
+#define QL_DIAG4_ARGS , off2, din
+#define QL_DIAG4_STEP off2 += rowstep_out * 4u;
+#else
+#define QL_DIAG4_ARGS
+#define QL_DIAG4_STEP
+#endif
 #define QL_ROW(PH)                                                                         \
     {                                                                                      \
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
         ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm,       \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
-                                   dirty, o);                                              \
+                                   dirty, o QL_DIAG4_ARGS);                                \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
         wq[(PH + kWD) % 5] = ld_u32(wordsT + ((pos + kWD) >> 4) * (unsigned)NT, tid4); /* row j + kWD */ \
         off += rowstep * 4u;                                                                     \
+        QL_DIAG4_STEP                                                                            \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
         /* cross-row traffic is the explicit prefetch above (register budget);      */     \
@@ -564,8 +598,13 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             if (Lwave == 0u) continue; // no lane of this wavefront has a query
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
+#if DCP_QLANE_DIAG & 4
+#define QL_DIAG4_TILE , (t & 1u)
+#else
+#define QL_DIAG4_TILE
+#endif
 #define QL_SWEEP(F, L_)                                                                          \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o)
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o QL_DIAG4_TILE)
             if (first && last) QL_SWEEP(true, true);
             else if (first) QL_SWEEP(true, false);
             else if (last) QL_SWEEP(false, true);

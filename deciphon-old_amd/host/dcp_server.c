@@ -99,6 +99,7 @@ enum rc prod_fclose(void)
     {
         char buf[1 << 16];
         size_t n;
+        if (!prod_file[i].fp) continue; /* a thread that was never opened (on-demand use) wrote nothing */
         if (fflush(prod_file[i].fp)) rc = fail(RC_EIO, "failed to flush");
         rewind(prod_file[i].fp);
         while (!rc && (n = fread(buf, 1, sizeof buf, prod_file[i].fp)) > 0)

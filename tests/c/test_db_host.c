@@ -373,8 +373,51 @@ static void lip_primitives(void)
     remove(path);
 }
 
+/* products without any device call: prod_fwrite's row format (src/server/prod.c:13-41,153-181), the
+ * caller's write_match_func once per step with ';' between steps, on-demand opening of a thread's file,
+ * prod_fclose = header + rows in thread order */
+static enum rc step_len_func(FILE *fp, void const *match)
+{
+    struct match const *m = match;
+    return fprintf(fp, "%.*s/%u", (int)m->frag->size, m->frag->str, (unsigned)m->step->seqlen) < 0 ? RC_EIO : RC_OK;
+}
+
+static void products(void)
+{
+    struct prod p = {0};
+    prod_setup_job(&p, "dna", "protein", 5);
+    prod_setup_seq(&p, 7);
+    snprintf(p.profile_name, sizeof p.profile_name, "PF1");
+    p.alt_loglik = -54.35543441772461;
+    p.null_loglik = -48.927268981933594;
+    struct imm_step st[4] = {{PROTEIN_S_STATE, 0}, {PROTEIN_N_STATE, 3}, {PROTEIN_N_STATE, 1}, {PROTEIN_T_STATE, 0}};
+    struct imm_path path = {st, 4, 4};
+    struct imm_seq seq = imm_seq(imm_str("ACGT"), imm_super(imm_super(&imm_dna_iupac)));
+    struct match m;
+    match_setup(&m, NULL);
+    CHECK(prod_fwrite(&p, &seq, &path, 3, step_len_func, &m) == RC_OK); /* threads 0..2 never opened */
+    prod_setup_seq(&p, 8);
+    CHECK(prod_fwrite(&p, &seq, &path, 1, step_len_func, &m) == RC_OK);
+    struct imm_path too_long = {st, 4, 4};
+    struct imm_seq shorter = imm_subseq(&seq, 0, 3);
+    CHECK(prod_fwrite(&p, &shorter, &too_long, 1, step_len_func, &m) == RC_EINVAL); /* path longer than the sequence */
+    CHECK(prod_fclose() == RC_OK);
+    char buf[1024] = {0};
+    CHECK(fread(buf, 1, sizeof buf - 1, prod_final_fp()) > 0);
+    char const *want_rows = "5\t8\tPF1\tdna\t-54.355434417724609\t-48.927268981933594\tprotein\t" DECIPHON_VERSION "\t/0;ACG/3;T/1;/0\n";
+    CHECK(!strncmp(buf, prod_header(), strlen(prod_header())));
+    CHECK(!strncmp(buf + strlen(prod_header()), want_rows, strlen(want_rows))); /* thread 1 before thread 3 */
+    CHECK(strstr(buf, "5\t7\tPF1\tdna\t") > strstr(buf, "5\t8\tPF1\tdna\t"));
+    CHECK(access(prod_final_path(), R_OK) == 0);
+    char path_copy[64];
+    snprintf(path_copy, sizeof path_copy, "%s", prod_final_path());
+    prod_final_cleanup();
+    CHECK(access(path_copy, R_OK) != 0 && prod_final_fp() == NULL);
+}
+
 int main(void)
 {
+    products();
     lip_primitives();
     header_checks();
     roundtrip();
