@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--qstep", type=int, default=0, help="override queries per step per GPU (debug)")
     ap.add_argument("--qlen", type=int, default=0, help="override query length (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "rowsweep", "qlane"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "rowsweep", "qlane", "qlane2"],
                     help="dcp_scan_params.kernel (auto = the library's cost model)")
     ap.add_argument("--hit-gather", default="c", choices=["c", "torch"],
                     help="N>1: hit gather through the C host's RCCL path (dcp_dist_*) or torch.distributed")
@@ -306,7 +306,8 @@ def main():
                 cdist.close()
             cdist = None
             gather_kind += f" (C RCCL communicator unavailable{': ' + why if why else ''})"
-    kernel_id = {"auto": dcp.KERNEL_AUTO, "rowsweep": dcp.KERNEL_ROWSWEEP, "qlane": dcp.KERNEL_QLANE}[args.kernel]
+    kernel_id = {"auto": dcp.KERNEL_AUTO, "rowsweep": dcp.KERNEL_ROWSWEEP, "qlane": dcp.KERNEL_QLANE,
+                 "qlane2": dcp.KERNEL_QLANE2}[args.kernel]
 
     def step(i):
         sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep),

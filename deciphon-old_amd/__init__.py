@@ -86,7 +86,7 @@ class ScanParams(C.Structure):
                 ("lrt_threshold", C.c_float), ("keep_scores", C.c_int), ("kernel", C.c_int)]
 
 
-KERNEL_AUTO, KERNEL_ROWSWEEP, KERNEL_QLANE = 0, 1, 2
+KERNEL_AUTO, KERNEL_ROWSWEEP, KERNEL_QLANE, KERNEL_QLANE2 = 0, 1, 2, 3
 
 
 class Hit(C.Structure):

@@ -671,7 +671,9 @@ int dcp_gpu_seqs_set_xtrans(dcp_gpu_ctx *c, float const *xt, unsigned nseqs)
         for (int i = 0; i < DCP_NXTRANS; ++i)
         {
             float const v = xt[(size_t)q * DCP_NXTRANS + i];
-            if (v != v) return c->fail(DCP_EINVAL, "NaN special transition");
+            uint32_t bits; // this file is built with -fno-honor-nans: test the encoding, not v != v
+            std::memcpy(&bits, &v, sizeof bits);
+            if ((bits & 0x7fffffffu) > 0x7f800000u) return c->fail(DCP_EINVAL, "NaN special transition");
             buf[(size_t)q * DCP_XSTRIDE + i] = v;
         }
     HIP_TRY(c, hipMemcpy(c->d_xtrans.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -794,6 +796,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             if (lmax > 200000u) kernel = 1;
         }
     }
+    if (kernel < 1 || kernel > 3) return c->fail(DCP_EINVAL, "unknown kernel %d", kernel);
+    bool const two_stage = kernel == 3; // the query-lane kernel's two-stage variant (dcp_qlane.hip)
+    if (two_stage) kernel = 2;
     c->last_kernel = kernel;
     if (kernel == 2)
     {
@@ -911,7 +916,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const per_block = (uint64_t)dcp_qlane_scratch_planes() * ((uint64_t)qa.lmax + 8u) * NT; // floats
         uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
         uint64_t fit = per_block ? budget / per_block : 0;
-        unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, 2ull * c->num_cus), fit);
+        // one 512-thread block per CU (two-stage) or two 256-thread blocks (single-stage)
+        uint64_t const resident_blocks = two_stage ? (uint64_t)c->num_cus : 2ull * c->num_cus;
+        unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, resident_blocks), fit);
         if (nblocks == 0)
             return c->fail(DCP_ENOMEM, "sequence of %u nt is too long for the query-lane kernel: use kernel = 1", qa.lmax);
         size_t const need = (size_t)nblocks * per_block;
@@ -919,7 +926,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-        if (dcp_launch_qlane(&qa, nblocks, c->stream)) return c->fail(DCP_EFAIL, "query-lane launch failed");
+        if (two_stage ? dcp_launch_qlane2(&qa, nblocks, c->stream) : dcp_launch_qlane(&qa, nblocks, c->stream))
+            return c->fail(DCP_EFAIL, "query-lane launch failed");
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));
         c->launched_class[c->n_launched++] = -1;

@@ -157,6 +157,58 @@ struct Ring
     float B[5], Xm[5], Xd[5], Em[5];
 };
 
+// Where a tile's boundary values (Xm, Xd, Em per row and lane) come from / go to:
+//   IO_HBM  the per-block scratch planes in global memory (the single-stage kernel, and the
+//           odd -> even tile boundary of the two-stage kernel)
+//   IO_LDS  a ring of kRD rows in LDS between the two stages of a block of the two-stage kernel
+//           (viterbi_qlane2_kernel): stage 0 sweeps the even tiles, stage 1 the odd ones a few rows
+//           behind, so half of all boundaries never leave the CU
+enum
+{
+    IO_HBM = 1,
+    IO_LDS = 2
+};
+constexpr unsigned kRD = 16;      // rows of the LDS ring (power of two)
+constexpr unsigned kRLanes = 256; // lanes (queries) per stage
+constexpr unsigned kRingPlaneBytes = kRD * kRLanes * 4u;
+constexpr unsigned kRingSkew = 8; // rows the consumer stage starts behind the producer
+typedef float __attribute__((address_space(3))) lds_float;
+typedef unsigned __attribute__((address_space(3))) lds_uint;
+
+// One wavefront's end of the ring.  Producer lane i and consumer lane i hold the same query, so the
+// hand-off is wave to wave: `flag_mine[lane]` = last row this side has written (producer) / taken
+// (consumer), `flag_peer` = the partner wavefront's.  LDS executes one wavefront's operations in
+// order: data first, flag second is all the release a producer needs; the consumer's acquire is the
+// wait for the flag's value before it issues its data reads.
+struct LdsLink
+{
+    lds_float *ring;       // 3 planes of [kRD][kRLanes] floats, + this lane
+    lds_uint *flag_mine;   // + this lane
+    lds_uint *flag_peer;   // first lane of the partner wavefront (read as a broadcast)
+    unsigned roff;         // byte offset of the slot this row touches: (row % kRD) * 1024, lane folded into `ring`
+    unsigned seen;         // wave-uniform: the partner's progress as last read
+};
+
+__device__ __forceinline__ unsigned ring_wait(lds_uint *flag, unsigned need)
+{
+    unsigned v = __builtin_amdgcn_readfirstlane(*(lds_uint volatile *)flag);
+    while (v < need)
+    {
+        __builtin_amdgcn_s_sleep(1);
+        v = __builtin_amdgcn_readfirstlane(*(lds_uint volatile *)flag);
+    }
+    asm volatile("" ::: "memory"); // acquire: the ring reads that follow stay behind the flag read
+    return v;
+}
+__device__ __forceinline__ float ring_ld(lds_float *ring, unsigned boff)
+{
+    return *(lds_float volatile *)((char __attribute__((address_space(3))) *)ring + boff);
+}
+__device__ __forceinline__ void ring_st(lds_float *ring, unsigned boff, float v)
+{
+    *(lds_float volatile *)((char __attribute__((address_space(3))) *)ring + boff) = v;
+}
+
 template <bool FIRST>
 __device__ __forceinline__ void ring_fetch_x(Ring &r, int slot, float const *pXm, float const *pXd,
                                              float const *pEm, unsigned off)
@@ -230,12 +282,13 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, int PH, int NT, int D>
+template <int G, bool FIRST, bool LAST, int PH, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned &off, LaneXt const &xt,
-                                       bool live, bool at_end, bool &dirty, SweepOut &o
+                                       bool live, bool at_end, bool &dirty, SweepOut &o,
+                                       LdsLink const &lk, unsigned jrow
 #if DCP_QLANE_DIAG & 4
                                        , unsigned &off2, unsigned din
 #endif
@@ -262,8 +315,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // sequence word, issued D and five rows ago: everything but the VMEM operations of the D - 1
     // rows in between (loads and stores count alike, in issue order).
     {
-        constexpr int per_row = (FIRST ? 0 : 3) + (LAST ? 0 : 3) + ((!kRecomputeB && !FIRST) ? 1 : 0) +
-                                ((!kRecomputeB && FIRST) ? 1 : 0) + 1;
+        constexpr int per_row = ((FIRST || IN != IO_HBM) ? 0 : 3) + ((LAST || OUT != IO_HBM) ? 0 : 3) +
+                                ((!kRecomputeB && !FIRST) ? 1 : 0) + ((!kRecomputeB && FIRST) ? 1 : 0) + 1;
         constexpr int vm = ((D < (int)kWD ? D : (int)kWD) - 1) * per_row; // <= 32
         constexpr int lgkm = G > 1 ? 5 : 0;
         __builtin_amdgcn_s_waitcnt((vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (lgkm << 8));
@@ -339,7 +392,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // until the last node: its slot is refilled at the end of the row.)
     // (The row offset D rows ahead is folded into the plane pointers; the asm works on `off`
     // itself, so no copy of it is made.)
-    if constexpr (!FIRST)
+    if constexpr (!FIRST && IN == IO_HBM)
     {
         asm volatile("" : "+v"(off) : "v"(E));
 #if DCP_QLANE_DIAG & 4
@@ -354,6 +407,16 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); // lgkmcnt(0)
     go = gather_off(wn);
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
+    if constexpr (!FIRST && IN == IO_LDS)
+    {
+        // row j+1's boundary from the LDS ring (the sweep loop made sure the producer has written it);
+        // then tell the producer the slot is taken -- LDS runs these in order
+        constexpr int sl = (PH + 1) % 5;
+        ring.Xm[sl] = ring_ld(lk.ring, lk.roff);
+        ring.Xd[sl] = ring_ld(lk.ring, lk.roff + kRingPlaneBytes);
+        ring.Em[sl] = ring_ld(lk.ring, lk.roff + 2u * kRingPlaneBytes);
+        *(lds_uint volatile *)lk.flag_mine = jrow + 1u;
+    }
 
 #pragma unroll
     for (int g = 1; g < G; ++g)
@@ -374,14 +437,26 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     if constexpr (!LAST)
     {
         // edges into the next tile's first node
+        float const oXm = mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]);
+        float const oXd = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
+        if constexpr (OUT == IO_LDS)
+        {
+            ring_st(lk.ring, lk.roff, oXm);
+            ring_st(lk.ring, lk.roff + kRingPlaneBytes, oXd);
+            ring_st(lk.ring, lk.roff + 2u * kRingPlaneBytes, E);
+            *(lds_uint volatile *)lk.flag_mine = jrow; // after the data: LDS keeps this wavefront's order
+        }
+        else
+        {
 #if DCP_QLANE_DIAG & 4
-        unsigned const offw = off2;
+            unsigned const offw = off2;
 #else
-        unsigned const offw = off;
+            unsigned const offw = off;
 #endif
-        st_off(pXm, offw, mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]));
-        st_off(pXd, offw, fmaxf(pm + tr.md[KT], pd + tr.dd[KT]));
-        st_off(pEm, offw, E);
+            st_off(pXm, offw, oXm);
+            st_off(pXd, offw, oXd);
+            st_off(pEm, offw, E);
+        }
     }
     else
     {
@@ -402,12 +477,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST, int NT, int D>
+template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
                                          uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
-                                         SweepOut &o
+                                         SweepOut &o, LdsLink lk
 #if DCP_QLANE_DIAG & 4
                                          , unsigned tile_odd
 #endif
@@ -479,9 +554,26 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     }
     GatherOff go = gather_off(w);
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
+    if constexpr (!FIRST && IN == IO_LDS)
+    {
+        // start kRingSkew rows behind the producer, then row 1 -> slot 1
+        unsigned const need0 = Lwave < kRingSkew ? Lwave : kRingSkew;
+        lk.seen = ring_wait(lk.flag_peer, need0);
+        lk.roff = 1u * kRLanes * 4u;
+        ring.Xm[1] = ring_ld(lk.ring, lk.roff);
+        ring.Xd[1] = ring_ld(lk.ring, lk.roff + kRingPlaneBytes);
+        ring.Em[1] = ring_ld(lk.ring, lk.roff + 2u * kRingPlaneBytes);
+        *(lds_uint volatile *)lk.flag_mine = 1u;
+        lk.roff = 2u * kRLanes * 4u; // row 1 reads row 2's slot
+    }
+    else
+    {
+        lk.roff = 1u * kRLanes * 4u; // a producer's row 1 writes slot 1
+        lk.seen = 0u;
 #pragma unroll
-    for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
-        ring_fetch<FIRST>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * rowstep * 4u);
+        for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
+            ring_fetch<(FIRST || IN != IO_HBM)>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * rowstep * 4u);
+    }
 
 #if DCP_QLANE_DIAG & 4
 #define QL_DIAG4_ARGS , off2, din
@@ -494,9 +586,20 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     {                                                                                      \
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
-        ql_row<G, FIRST, LAST, PH, NT, D>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm,       \
+        if constexpr (!FIRST && IN == IO_LDS)                                               \
+        {   /* this row prefetches ring row j+1: the producer must have written it */       \
+            unsigned const need = pos < Lwave ? pos : Lwave;                                \
+            if (lk.seen < need) lk.seen = ring_wait(lk.flag_peer, need);                   \
+        }                                                                                  \
+        if constexpr (!LAST && OUT == IO_LDS)                                               \
+        {   /* this row writes slot j % kRD: the consumer must have taken row j - kRD */    \
+            if (j > lk.seen + kRD) lk.seen = ring_wait(lk.flag_peer, j - kRD);             \
+        }                                                                                  \
+        ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm, \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
-                                   dirty, o QL_DIAG4_ARGS);                                \
+                                   dirty, o, lk, j QL_DIAG4_ARGS);                         \
+        if constexpr ((!FIRST && IN == IO_LDS) || (!LAST && OUT == IO_LDS))                 \
+            lk.roff = (lk.roff + kRLanes * 4u) & (kRingPlaneBytes - 1u);                   \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
         wq[(PH + kWD) % 5] = ld_u32(wordsT + ((pos + kWD) >> 4) * (unsigned)NT, tid4); /* row j + kWD */ \
         off += rowstep * 4u;                                                                     \
@@ -604,7 +707,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 #define QL_DIAG4_TILE
 #endif
 #define QL_SWEEP(F, L_)                                                                          \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o QL_DIAG4_TILE)
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{} QL_DIAG4_TILE)
             if (first && last) QL_SWEEP(true, true);
             else if (first) QL_SWEEP(true, false);
             else if (last) QL_SWEEP(false, true);
@@ -628,6 +731,147 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             if (a.out_null) a.out_null[oi] = nul;
             if (a.out_alt) a.out_alt[oi] = alt;
             // xmath_lrt_f32 + filter of scan_thread.c:121-123
+            float const lrt = -2 * (nul - alt);
+            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+            {
+                unsigned const h = atomicAdd(a.nhits, 1u);
+                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two-stage variant: a block is 512 threads = 2 stages x 256 queries on ONE profile.  Stage 0 (waves
+// 0-3) sweeps the even tiles, stage 1 (waves 4-7) the odd tiles a few rows behind; wave w of stage 1
+// holds the same 64 queries as wave w of stage 0 and shares its SIMD.  The boundary stage 0 -> stage 1
+// (tile 2k -> 2k+1) goes through a 16-row LDS ring with per-wavefront progress flags; only the
+// boundary stage 1 -> stage 0 (tile 2k+1 -> 2k+2) still goes through the HBM scratch planes: half of
+// the single-stage kernel's HBM traffic.  Both tile images live in LDS (2 x 43.6 KB + the ring's 48 KB:
+// one block per CU, still two wavefronts per SIMD).  A step = one tile per stage between two block
+// barriers; the arithmetic of a row is ql_row's, unchanged, so results are bit-identical.
+// Measured motive (profiles/r02/diag_builds.txt): with the planes collapsed to one row (no HBM traffic)
+// the single-stage kernel runs 26 % faster, with every other boundary collapsed 12 % faster.
+// ---------------------------------------------------------------------------------------------------
+template <int G, int D>
+__global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a)
+{
+    constexpr int NT = (int)kRLanes; // lanes per stage
+    constexpr int KT = 4 * G;
+    constexpr int TAB_FLOATS = G * NC * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[]; // dcp_qlane2_lds_bytes()
+    __shared__ unsigned s_task;
+    unsigned const tid = threadIdx.x & (unsigned)(NT - 1); // lane within the stage = query slot of the block
+    unsigned const stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    float *const tabM = lds + stage * TAB_FLOATS;
+    float2 *const tabIN = reinterpret_cast<float2 *>(lds + 2 * TAB_FLOATS); // [code] = {insert, background}
+    float *const ringf = lds + 2 * TAB_FLOATS + 2 * NC;
+    unsigned *const flagP = reinterpret_cast<unsigned *>(ringf + 3 * kRD * NT); // producer (stage 0) rows written
+    unsigned *const flagC = flagP + NT;                                       // consumer (stage 1) rows taken
+    float *const rnull = reinterpret_cast<float *>(flagC + NT);               // null score: stage 0 -> final stage
+    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
+    float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane;
+    unsigned const wave_lane0 = tid & ~63u;
+
+    LdsLink lk;
+    lk.ring = (lds_float *)(ringf + tid);
+    lk.flag_mine = (lds_uint *)((stage == 0u ? flagP : flagC) + tid);
+    lk.flag_peer = (lds_uint *)((stage == 0u ? flagC : flagP) + wave_lane0);
+    lk.roff = 0u;
+    lk.seen = 0u;
+
+    for (;;)
+    {
+        if (threadIdx.x == 0) s_task = atomicAdd(a.task_counter, 1u);
+        __syncthreads();
+        unsigned const task = __builtin_amdgcn_readfirstlane(s_task);
+        __syncthreads();
+        if (task >= a.ntasks) break;
+        unsigned const slot = a.nprof - 1u - task / a.nqblocks; // biggest profiles first
+        unsigned const qb = task % a.nqblocks;
+        dcp_ql_prof const pm = a.profs[slot];
+        unsigned const T = pm.ntiles;
+
+        unsigned const qi = qb * (unsigned)NT + tid;
+        bool const has = qi < a.nseqs;
+        unsigned const q = has ? a.qorder[qi] : 0u;
+        unsigned const L = has ? a.seq_len[q] : 0u;
+        uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
+        LaneXt xt;
+        {
+            float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
+            xt.RR = x[DCP_X_RR], xt.SB = x[DCP_X_SB], xt.SN = x[DCP_X_SN], xt.NN = x[DCP_X_NN];
+            xt.NB = x[DCP_X_NB], xt.ET = x[DCP_X_ET], xt.EC = x[DCP_X_EC], xt.CC = x[DCP_X_CC];
+            xt.CT = x[DCP_X_CT], xt.EB = x[DCP_X_EB], xt.EJ = x[DCP_X_EJ], xt.JJ = x[DCP_X_JJ];
+            xt.JB = x[DCP_X_JB];
+        }
+        {
+            float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
+            float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
+            for (unsigned i = threadIdx.x; i < (unsigned)NC; i += 512u)
+                tabIN[i] = float2{gi[i], gn[i]};
+        }
+
+        SweepOut o{ninf(), ninf(), ninf()};
+        bool dirty = false;
+        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
+        unsigned const nsteps = (T + 1u) / 2u;
+        for (unsigned st = 0; st < nsteps; ++st)
+        {
+            unsigned const t = 2u * st + stage;
+            bool const mine = t < T; // the last step of an odd profile has no odd tile
+            __syncthreads();       // previous step: both stages are done with their images and with the ring
+            if (mine)
+            {
+                float4 const *__restrict__ src =
+                    reinterpret_cast<float4 const *>(a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
+                float4 *dst = reinterpret_cast<float4 *>(tabM);
+                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
+                    dst[i] = src[i];
+            }
+            *(lds_uint volatile *)lk.flag_mine = 0u; // row counters restart with every step
+            __syncthreads();
+            if (Lwave == 0u || !mine) continue;
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
+            bool const first = t == 0u, last = t + 1u == T;
+#if DCP_QLANE_DIAG & 4
+#error "the two-stage kernel has no DIAG=4 build"
+#endif
+#define QL2_SWEEP(F, L_, IN_, OUT_)                                                                       \
+    ql_sweep<G, F, L_, NT, D, IN_, OUT_>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
+            if (stage == 0u)
+            {
+                if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM);
+                else if (first) QL2_SWEEP(true, false, IO_HBM, IO_LDS);
+                else if (last) QL2_SWEEP(false, true, IO_HBM, IO_HBM);
+                else QL2_SWEEP(false, false, IO_HBM, IO_LDS);
+                if (first) rnull[tid] = o.Rn;
+            }
+            else
+            {
+                if (last) QL2_SWEEP(false, true, IO_LDS, IO_HBM);
+                else QL2_SWEEP(false, false, IO_LDS, IO_HBM);
+            }
+#undef QL2_SWEEP
+        }
+        __syncthreads(); // rnull is visible; nobody is still reading tabIN
+
+        unsigned const final_stage = (T - 1u) & 1u; // the stage that swept the last tile
+        if (stage != final_stage) continue;
+        if (has && dirty)
+        {
+            unsigned const cls = pm.cls;
+            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
+            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
+            else *a.redo_overflow = 1u;
+        }
+        else if (has)
+        {
+            float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
+            float const nul = rnull[tid];
+            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
+            if (a.out_null) a.out_null[oi] = nul;
+            if (a.out_alt) a.out_alt[oi] = alt;
             float const lrt = -2 * (nul - alt);
             if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
             {
@@ -679,6 +923,27 @@ extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream
 {
     hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0,
                        (hipStream_t)stream, *a);
+}
+
+extern "C" unsigned dcp_qlane2_lds_bytes(void)
+{
+    // two tile images, the insert/background table, the ring's three planes, two flag arrays, the null scores
+    return (unsigned)(sizeof(float) * (2u * 2u * NC * 4u + 2u * NC + 3u * kRD * kRLanes + 3u * kRLanes));
+}
+
+extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream)
+{
+    auto kern = viterbi_qlane2_kernel<2, DCP_QLANE_D>;
+    static bool configured = false;
+    unsigned const lds = dcp_qlane2_lds_bytes();
+    if (!configured)
+    {
+        if (hipFuncSetAttribute((void const *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return 1;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, (hipStream_t)stream, *a);
+    return 0;
 }
 
 extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)

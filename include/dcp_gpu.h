@@ -262,8 +262,9 @@ struct dcp_scan_params
     float lrt_threshold; /* scan.c:221 passes 10.0 */
     int keep_scores;     /* also keep dense null/alt score matrices */
     int kernel;          /* 0 = choose by a cost model (DB size x batch size); 1 = row sweep (one wavefront
-                          * group per pair: any batch size); 2 = query lane (one
-                          * lane per query, tiles in LDS: throughput path) */
+                          * group per pair: any batch size); 2 = query lane (one lane per query, tiles in
+                          * LDS: throughput path); 3 = query lane, two-stage blocks (even / odd tiles of a
+                          * profile pipelined through an LDS ring: half the scratch traffic) */
 };
 
 /* scan_thread.c:121-123 keeps a pair iff lrt is finite and >= threshold */

@@ -355,12 +355,12 @@ static void scan_threads(void)
     text = slurp(prod_final_fp());
     hit = strstr(text, "78\t200\tPF00003\t");
     CHECK(hit != NULL && g_custom_steps > 10);
-    if (hit)
     {
-        unsigned seps = 0;
-        for (char *c = strrchr(hit, '\t'); c && *c && *c != '\n'; ++c)
-            seps += *c == ';';
-        CHECK(seps + 1 == g_custom_steps);
+        /* one call per path step over all rows: steps = ';' separators + one per row */
+        unsigned seps = 0, nrows = 0;
+        for (char *c = text + strlen(prod_header()); *c; ++c)
+            seps += *c == ';', nrows += *c == '\n';
+        CHECK(nrows >= 1 && seps + nrows == g_custom_steps);
     }
     free(text);
     prod_final_cleanup();

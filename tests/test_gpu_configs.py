@@ -6,7 +6,7 @@ configs[4] "C5"  M 50-2000 x queries 100 nt-10 kbp, 8 GPUs               -> test
 (configs[0] = the reference's golden test: tests/test_golden_fixtures.py, tests/test_c_host.py;
  configs[2] "C3" = test_gpu_parity.py::test_full_size_c3_step_both_kernels_agree.)
 
-Every test runs BOTH device kernels (row sweep, query lane + redo) through the C-ABI, requires them to
+Every test runs ALL device kernels (row sweep, query lane + redo, two-stage query lane + redo) through the C-ABI, requires them to
 agree bit for bit on every pair and on the hit list, and compares a sample of pairs -- always including
 the extreme ones -- with the oracle's independent model build and Viterbi (<= 5e-5 relative, the
 reference's float32 bar, test/hope_support.h:26).  Generators: bench.py.
@@ -21,13 +21,14 @@ REL = 5e-5
 
 def scan_both(dcp, sc):
     out = {}
-    for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
+    for name, k in (("qlane", dcp.KERNEL_QLANE), ("qlane2", dcp.KERNEL_QLANE2), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
         sc.scan(True, False, 10.0, kernel=k)
         n, a = sc.scores()
         out[name] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
-    assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
-    assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
-    assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
+    for other in ("qlane2", "rowsweep"):
+        assert np.array_equal(out["qlane"][0], out[other][0]), other
+        assert np.array_equal(out["qlane"][1], out[other][1]), other
+        assert np.array_equal(out["qlane"][2], out[other][2]), other
     nul, alt = out["qlane"][0].view(np.float32), out["qlane"][1].view(np.float32)
     assert np.isfinite(alt).all() and np.isfinite(nul).all()
     return nul, alt, out["qlane"][2]

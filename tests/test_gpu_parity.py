@@ -26,11 +26,11 @@ def scanner(dcp):
     s.close()
 
 
-@pytest.fixture(params=["rowsweep", "qlane"])
+@pytest.fixture(params=["rowsweep", "qlane", "qlane2"])
 def kern(request, dcp):
-    """Every parity test runs on both kernels: the row sweep (one wavefront group per pair) and
-    the query-lane throughput kernel (forced even for tiny batches)."""
-    return dcp.KERNEL_ROWSWEEP if request.param == "rowsweep" else dcp.KERNEL_QLANE
+    """Every parity test runs on every kernel: the row sweep (one wavefront group per pair), the
+    query-lane throughput kernel and its two-stage variant (both forced even for tiny batches)."""
+    return {"rowsweep": dcp.KERNEL_ROWSWEEP, "qlane": dcp.KERNEL_QLANE, "qlane2": dcp.KERNEL_QLANE2}[request.param]
 
 
 def rand_seqs(rng, n, lo, hi):
@@ -220,7 +220,7 @@ def test_hits_and_lrt_filter(dcp, oracle32, scanner, kern):
         # the query-lane kernel hands pairs with E -> B / J -> B feedback (the two-domain query
         # at least) to the row sweep; uni-hit scans and row-sweep scans have no redo pairs
         redo = scanner.last_scan_redo_pairs
-        assert (redo >= 1) if (multi and kern == dcp.KERNEL_QLANE) else (redo == 0)
+        assert (redo >= 1) if (multi and kern in (dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2)) else (redo == 0)
         assert redo < len(seqs) * len(profiles)
         on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
         assert same_bits(gn, on) and same_bits(ga, oa)
@@ -578,7 +578,8 @@ def test_qlane_at_block_scale(dcp, oracle32, scanner):
     scanner.upload_db(profiles)
     scanner.upload_seqs(seqs)
     out = {}
-    for name, k in (("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE), ("auto", dcp.KERNEL_AUTO)):
+    for name, k in (("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE), ("qlane2", dcp.KERNEL_QLANE2),
+                    ("auto", dcp.KERNEL_AUTO)):
         scanner.scan(True, False, 10.0, kernel=k)
         out[name] = scanner.scores() + (scanner.hits(),)
     for name in ("qlane", "auto"):
@@ -634,7 +635,7 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
         sc.upload_db(profiles)
         sc.upload_seqs_flat(queries.reshape(-1), (np.arange(1001, dtype=np.uint64) * 1000).astype(np.uint32))
         out = {}
-        for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
+        for name, k in (("qlane", dcp.KERNEL_QLANE), ("qlane2", dcp.KERNEL_QLANE2), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
             sc.scan(True, False, 10.0, kernel=k)
             n, a = sc.scores()
             out[name] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
@@ -646,9 +647,10 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
         assert sc.launch_infos()[0]["W"] == 0
         sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 32))
         assert sc.launch_infos()[0]["W"] >= 1
-        assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
-        assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
-        assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
+        for other in ("qlane2", "rowsweep"):
+            assert np.array_equal(out["qlane"][0], out[other][0]), other
+            assert np.array_equal(out["qlane"][1], out[other][1]), other
+            assert np.array_equal(out["qlane"][2], out[other][2]), other
         assert np.isfinite(out["qlane"][1].view(np.float32)).all()
         rng = np.random.default_rng(7)
         alt = out["qlane"][1].view(np.float32)
@@ -686,13 +688,14 @@ def test_mixed_length_stress_both_kernels_agree(dcp):
         del profiles
         sc.upload_seqs(queries)
         out = {}
-        for name, k in (("qlane", dcp.KERNEL_QLANE), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
+        for name, k in (("qlane", dcp.KERNEL_QLANE), ("qlane2", dcp.KERNEL_QLANE2), ("rowsweep", dcp.KERNEL_ROWSWEEP)):
             sc.scan(True, False, 10.0, kernel=k)
             n, a = sc.scores()
             out[name] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
-        assert np.array_equal(out["qlane"][0], out["rowsweep"][0])
-        assert np.array_equal(out["qlane"][1], out["rowsweep"][1])
-        assert np.array_equal(out["qlane"][2], out["rowsweep"][2])
+        for other in ("qlane2", "rowsweep"):
+            assert np.array_equal(out["qlane"][0], out[other][0]), other
+            assert np.array_equal(out["qlane"][1], out[other][1]), other
+            assert np.array_equal(out["qlane"][2], out[other][2]), other
         assert np.isfinite(out["qlane"][1].view(np.float32)).all()
     finally:
         sc.close()
