@@ -209,6 +209,11 @@ def main():
                     help="dcp_scan_params.kernel (auto = the library's cost model)")
     ap.add_argument("--hit-gather", default="c", choices=["c", "torch"],
                     help="N>1: hit gather through the C host's RCCL path (dcp_dist_*) or torch.distributed")
+    ap.add_argument("--dense", type=int, default=0, metavar="F",
+                    help="hit-dense stress: the DB is F distinct profiles replicated nprof/F times and EVERY query "
+                         "carries one family's consensus, so ~1/F of all pairs are real hits (redo-list regime); "
+                         "with --dense-random the same DB is scanned with random queries (the reference rate)")
+    ap.add_argument("--dense-random", action="store_true")
     ap.add_argument("--planted", action="store_true",
                     help="planted-hit variant: 1 %% of the queries carry a real hit (exercises hits / gather)")
     args = ap.parse_args()
@@ -249,9 +254,15 @@ def main():
     b, e = ddist.shard_range(sizes, world, rank)
     cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
     nthreads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
-    with ThreadPoolExecutor(max(1, nthreads // max(1, min(world, 8)))) as ex:
-        profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
-                               range(b, e)))
+    if args.dense:
+        fam = [dcp.ProteinProfile.sample(0xDEC1F0 + f, int(sizes[f]), cfg, f"FAM{f:02d}") for f in range(args.dense)]
+        sizes = np.array([sizes[p % args.dense] for p in range(nprof)], np.uint32)
+        b, e = ddist.shard_range(sizes, world, rank)
+        profiles = [fam[p % args.dense] for p in range(b, e)]
+    else:
+        with ThreadPoolExecutor(max(1, nthreads // max(1, min(world, 8)))) as ex:
+            profiles = list(ex.map(lambda p: dcp.ProteinProfile.sample(0xDEC1F0 + p, int(sizes[p]), cfg, f"PF{p:05d}"),
+                                   range(b, e)))
     t_build = time.perf_counter() - t0
     sc = dcp.Scanner(local_rank)
     t0 = time.perf_counter()
@@ -263,6 +274,15 @@ def main():
     nsteps = args.steps + args.warmup
     queries = make_queries(0, nsteps * qstep, qlen)
     planted = plant_hits(dcp, queries, 0, sizes, cfg) if (args.planted and qlen) else []
+    if args.dense and not args.dense_random and qlen:
+        # every query carries the most likely codon of each match state of family q % F
+        for f in range(args.dense):
+            md = fam[f].match_dist
+            codon = md[:, 4:].reshape(-1, 5, 5, 5)[:, :4, :4, :4].reshape(-1, 64).argmax(axis=1)
+            core = np.stack([(codon >> 4) & 3, (codon >> 2) & 3, codon & 3], axis=1).reshape(-1).astype(np.uint8)
+            core = core[: max(3, (qlen - 60) // 3 * 3)]
+            at = (qlen - len(core)) // 2
+            queries[f::args.dense, at:at + len(core)] = core
     if qlen:
         off = (np.arange(nsteps * qstep + 1, dtype=np.uint64) * qlen).astype(np.uint32)
         sc.upload_seqs_flat(queries.reshape(-1), off)
@@ -472,6 +492,8 @@ def main():
                             f"{qstep} distinct {str(qlen) + '-nt' if qlen else '100-10000-nt'} queries per step, multi_hits, lrt>=10",
                 "profiles_per_gpu": e - b, "queries_per_step": qstep, "query_len": qlen,
                 "kernel": args.kernel,
+                "dense_families": args.dense or None, "dense_queries": (None if not args.dense else
+                                                                         "random" if args.dense_random else "consensus"),
                 "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({gather_kind})" if (world > 1 or force_dist) else ""),
             },
             "roofline": roof,

@@ -143,6 +143,8 @@ __device__ __forceinline__ float ld_off(float const *base, unsigned boff)
 {
     return *reinterpret_cast<float const *>(reinterpret_cast<char const *>(base) + boff);
 }
+typedef uint32_t const __attribute__((address_space(1))) *gu32_ptr; // explicitly global: survives an asm pin
+typedef char const __attribute__((address_space(1))) *gchar_ptr;
 __device__ __forceinline__ unsigned ld_u32(uint32_t const *base, unsigned boff)
 {
     return *reinterpret_cast<uint32_t const *>(reinterpret_cast<char const *>(base) + boff);
@@ -171,42 +173,98 @@ enum
 constexpr unsigned kRD = 16;      // rows of the LDS ring (power of two)
 constexpr unsigned kRLanes = 256; // lanes (queries) per stage
 constexpr unsigned kRingPlaneBytes = kRD * kRLanes * 4u;
-constexpr unsigned kRingSkew = 8; // rows the consumer stage starts behind the producer
+// Tuning knobs of the ring hand-shake, measured on the C3 step (profiles/r02/qlane2_tuning.txt; ms of the
+// launch): waiting for more rows than needed is what costs -- hysteresis 4: 2603-2908, 1: 2520-2535,
+// 0: 2531; the initial skew (2..8 rows) and the poll sleep (0..4) do not matter; stages by wavefront
+// halves (0-3 / 4-7) are a little better than even / odd wavefronts (2520 vs 2535).
+#ifndef DCP_Q2_SKEW
+#define DCP_Q2_SKEW 4
+#endif
+#ifndef DCP_Q2_HYST
+#define DCP_Q2_HYST 1
+#endif
+#ifndef DCP_Q2_SLEEP
+#define DCP_Q2_SLEEP 2
+#endif
+#ifndef DCP_Q2_STAGEMAP
+#define DCP_Q2_STAGEMAP 1 // 0: even / odd wavefronts; 1: wavefronts 0-3 / 4-7
+#endif
+constexpr unsigned kRingSkew = DCP_Q2_SKEW; // rows the consumer stage starts behind the producer
+constexpr unsigned kRingHyst = DCP_Q2_HYST; // a side that has to wait waits for this many rows beyond what it needs
 typedef float __attribute__((address_space(3))) lds_float;
 typedef unsigned __attribute__((address_space(3))) lds_uint;
 
+typedef char __attribute__((address_space(3))) lds_char;
+
 // One wavefront's end of the ring.  Producer lane i and consumer lane i hold the same query, so the
-// hand-off is wave to wave: `flag_mine[lane]` = last row this side has written (producer) / taken
-// (consumer), `flag_peer` = the partner wavefront's.  LDS executes one wavefront's operations in
-// order: data first, flag second is all the release a producer needs; the consumer's acquire is the
-// wait for the flag's value before it issues its data reads.
+// hand-off is wave to wave: flagP[lane] = last row the producer has written, flagC[lane] = last row the
+// consumer has taken; a wavefront polls lane 0 of its partner (a broadcast read).  LDS executes one
+// wavefront's operations in order: data first, flag second is all the release a producer needs; the
+// consumer's acquire is the wait for the flag's value before it issues its data reads.
+// No per-lane register is spent on the ring: a row's slot is (row - 1) % kRD, and the scratch-plane
+// byte offset `off` = (row - 1) * 1024 + lane * 4 that every sweep keeps anyway yields both the slot
+// address (off & 0x3fff) and the lane's flag address (off & 0x3ff); the ring sits at the start of the
+// block's LDS so that planes and flags are immediate offsets of the ds instructions.
 struct LdsLink
 {
-    lds_float *ring;       // 3 planes of [kRD][kRLanes] floats, + this lane
-    lds_uint *flag_mine;   // + this lane
-    lds_uint *flag_peer;   // first lane of the partner wavefront (read as a broadcast)
-    unsigned roff;         // byte offset of the slot this row touches: (row % kRD) * 1024, lane folded into `ring`
+    lds_char *base;        // the block's LDS (a compile-time constant: the kernel's only LDS object)
+    unsigned my_flag;      // byte offset of this stage's flag array (wave-uniform)
+    unsigned peer_flag;    // byte offset of the partner wavefront's lane-0 flag (wave-uniform)
     unsigned seen;         // wave-uniform: the partner's progress as last read
 };
+// Block LDS of the two-stage kernel: all 160 KiB, laid out so that EVERY access keeps an immediate
+// offset.  Gathers address a tile image as (window bits) + 16-bit immediate: image 0 sits at 0, image 1
+// at 64 KiB with that base carried in the window register (gather_off<BASE>); the insert/background
+// table is reached from (window >> 1), i.e. from base/2 = 32 KiB for stage 1, so ONE copy at 43 648
+// serves both stages (immediates 43 648.. and 10 880..).  The ring's planes start at 7 x 16 KiB.
+constexpr unsigned kL2TabIN = 43648u;                 // = one tile image: 2 groups x 1364 codes x 16 B
+constexpr unsigned kL2FlagP = kL2TabIN + 2u * 1364u * 4u; // 54 560: producer flags [256]
+constexpr unsigned kL2FlagC = kL2FlagP + kRLanes * 4u;
+constexpr unsigned kL2Null = kL2FlagC + kRLanes * 4u;    // null scores, stage 0 -> final stage
+constexpr unsigned kL2Task = kL2Null + kRLanes * 4u;     // the task word
+constexpr unsigned kL2Tab1 = 65536u;                   // image of the odd tile
+constexpr unsigned kL2Ring = 7u * kRingPlaneBytes;     // 114 688 .. 163 840
+constexpr unsigned kL2Bytes = kL2Ring + 3u * kRingPlaneBytes;
+static_assert(kL2Task + 16u <= kL2Tab1 && kL2Tab1 + kL2TabIN <= kL2Ring && kL2Bytes == 160u * 1024u, "LDS layout");
 
-__device__ __forceinline__ unsigned ring_wait(lds_uint *flag, unsigned need)
+// The ring's flags are relaxed workgroup-scope atomics and its data plain LDS accesses: `volatile` would
+// make the backend's memory legalizer put s_waitcnt vmcnt(0) lgkmcnt(0) behind every access, which
+// drains the row's whole software pipeline (first version: 35 % slower than the single-stage kernel).
+// What is needed is ORDER only, and LDS gives it in hardware (one wavefront's operations execute in
+// order); the compiler is held to it by empty asm statements that clobber "memory".
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ unsigned flag_load(lds_uint *flag)
 {
-    unsigned v = __builtin_amdgcn_readfirstlane(*(lds_uint volatile *)flag);
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_store(lds_uint *flag, unsigned v)
+{
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned ring_wait(LdsLink const &lk, unsigned need)
+{
+    lds_uint *flag = (lds_uint *)(lk.base + lk.peer_flag);
+    unsigned v = __builtin_amdgcn_readfirstlane(flag_load(flag));
     while (v < need)
     {
-        __builtin_amdgcn_s_sleep(1);
-        v = __builtin_amdgcn_readfirstlane(*(lds_uint volatile *)flag);
+        __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
+        v = __builtin_amdgcn_readfirstlane(flag_load(flag));
     }
-    asm volatile("" ::: "memory"); // acquire: the ring reads that follow stay behind the flag read
+    compiler_fence(); // acquire: the ring reads that follow stay behind the flag read
     return v;
 }
-__device__ __forceinline__ float ring_ld(lds_float *ring, unsigned boff)
+// boundary values of the row whose scratch-plane byte offset is `rowoff`
+__device__ __forceinline__ float ring_ld(LdsLink const &lk, unsigned rowoff, unsigned plane)
 {
-    return *(lds_float volatile *)((char __attribute__((address_space(3))) *)ring + boff);
+    return *(lds_float *)(lk.base + ((rowoff & (kRingPlaneBytes - 1u)) | kL2Ring) + plane * kRingPlaneBytes);
 }
-__device__ __forceinline__ void ring_st(lds_float *ring, unsigned boff, float v)
+__device__ __forceinline__ void ring_st(LdsLink const &lk, unsigned rowoff, unsigned plane, float v)
 {
-    *(lds_float volatile *)((char __attribute__((address_space(3))) *)ring + boff) = v;
+    *(lds_float *)(lk.base + ((rowoff & (kRingPlaneBytes - 1u)) | kL2Ring) + plane * kRingPlaneBytes) = v;
+}
+__device__ __forceinline__ void ring_publish(LdsLink const &lk, unsigned rowoff, unsigned row)
+{
+    flag_store((lds_uint *)(lk.base + lk.my_flag + (rowoff & (kRLanes * 4u - 1u))), row);
 }
 
 template <bool FIRST>
@@ -241,13 +299,32 @@ struct GatherOff
 {
     unsigned a[5]; // (w & (4^(l+1) - 1)) * 16
 };
-__device__ __forceinline__ GatherOff gather_off(unsigned w)
+// BASE: LDS byte address of the tile image when it does not start at the block's LDS base (stage 1 of
+// the two-stage kernel: 64 KiB; a multiple of 16 KiB so that it does not overlap the window's 14 bits).
+// It rides in the window's high bits -- one v_lshl_or instead of the shift, and masks that keep it --
+// so that every gather keeps its 16-bit immediate offset.  The base is made opaque to the optimiser
+// (an SGPR that passed through an empty asm): knowing the constant, InstCombine rewrites
+// (w | B) & (m | B) into (w & m) | B and every gather pays a v_or (measured: +13 VALU per row).
+template <unsigned BASE> struct GatherMasks
 {
-    unsigned const w16 = w << 4;
+    unsigned base, m[4];
+    __device__ __forceinline__ GatherMasks()
+    {
+        static_assert((BASE & 0x3fffu) == 0u, "the base must not overlap the window's 14 bits");
+        base = BASE;
+        if constexpr (BASE != 0u) asm volatile("" : "+s"(base));
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            m[l] = (((1u << (2 * l + 2)) - 1u) << 4) | base;
+    }
+};
+template <unsigned BASE> __device__ __forceinline__ GatherOff gather_off(unsigned w, GatherMasks<BASE> const &gm)
+{
+    unsigned const w16 = (w << 4) | gm.base;
     GatherOff g;
 #pragma unroll
     for (int l = 0; l < 4; ++l)
-        g.a[l] = w16 & (((1u << (2 * l + 2)) - 1u) << 4);
+        g.a[l] = w16 & gm.m[l];
     g.a[4] = w16; // the window is 10 bits: all of it
     return g;
 }
@@ -282,13 +359,13 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, int PH, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM>
+template <int G, bool FIRST, bool LAST, int PH, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
                                        float *pXd, float *pEm, unsigned &off, LaneXt const &xt,
                                        bool live, bool at_end, bool &dirty, SweepOut &o,
-                                       LdsLink const &lk, unsigned jrow
+                                       LdsLink const &lk, unsigned jrow, GatherMasks<TBASE> const &gm
 #if DCP_QLANE_DIAG & 4
                                        , unsigned &off2, unsigned din
 #endif
@@ -405,17 +482,20 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // `in` is consumed: refill it for row j+1 while the other groups compute
     // group 1's gathers (issued at the top of the row) are the only LDS reads in flight: one wait
     __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); // lgkmcnt(0)
-    go = gather_off(wn);
+    go = gather_off<TBASE>(wn, gm);
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
     if constexpr (!FIRST && IN == IO_LDS)
     {
         // row j+1's boundary from the LDS ring (the sweep loop made sure the producer has written it);
         // then tell the producer the slot is taken -- LDS runs these in order
         constexpr int sl = (PH + 1) % 5;
-        ring.Xm[sl] = ring_ld(lk.ring, lk.roff);
-        ring.Xd[sl] = ring_ld(lk.ring, lk.roff + kRingPlaneBytes);
-        ring.Em[sl] = ring_ld(lk.ring, lk.roff + 2u * kRingPlaneBytes);
-        *(lds_uint volatile *)lk.flag_mine = jrow + 1u;
+        compiler_fence(); // not above the availability check of this row
+        unsigned const nxt = off + kRLanes * 4u; // row j+1
+        ring.Xm[sl] = ring_ld(lk, nxt, 0);
+        ring.Xd[sl] = ring_ld(lk, nxt, 1);
+        ring.Em[sl] = ring_ld(lk, nxt, 2);
+        compiler_fence();
+        ring_publish(lk, off, jrow + 1u);
     }
 
 #pragma unroll
@@ -441,10 +521,12 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         float const oXd = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
         if constexpr (OUT == IO_LDS)
         {
-            ring_st(lk.ring, lk.roff, oXm);
-            ring_st(lk.ring, lk.roff + kRingPlaneBytes, oXd);
-            ring_st(lk.ring, lk.roff + 2u * kRingPlaneBytes, E);
-            *(lds_uint volatile *)lk.flag_mine = jrow; // after the data: LDS keeps this wavefront's order
+            compiler_fence(); // not above the free-slot check of this row
+            ring_st(lk, off, 0, oXm);
+            ring_st(lk, off, 1, oXd);
+            ring_st(lk, off, 2, E);
+            compiler_fence();
+            ring_publish(lk, off, jrow); // after the data: LDS keeps this wavefront's order
         }
         else
         {
@@ -477,7 +559,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM>
+template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
                                          uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
@@ -539,7 +621,6 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
     // phi copy and costs a vmcnt(0) drain each time.)
     unsigned j = 1;
-    unsigned const tid4 = tid * 4u;
     unsigned const w0 = wordsT[tid];
     unsigned wq[5] = {w0, w0, w0, w0, w0}; // rows 1..5 take bases 2..6: all in word 0
     unsigned w = w0 & 3u & wmask;
@@ -552,23 +633,23 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         in.e0[l] = float4{ni, ni, ni, ni}, in.eI[l] = ni, in.eN[l] = ni;
         ring.B[l] = ring.Xm[l] = ring.Xd[l] = ring.Em[l] = ni;
     }
-    GatherOff go = gather_off(w);
+    GatherMasks<TBASE> const gm;
+    GatherOff go = gather_off<TBASE>(w, gm);
     ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
     if constexpr (!FIRST && IN == IO_LDS)
     {
         // start kRingSkew rows behind the producer, then row 1 -> slot 1
+        static_assert(NT == (int)kRLanes, "the ring's row stride is the scratch planes' row stride");
         unsigned const need0 = Lwave < kRingSkew ? Lwave : kRingSkew;
-        lk.seen = ring_wait(lk.flag_peer, need0);
-        lk.roff = 1u * kRLanes * 4u;
-        ring.Xm[1] = ring_ld(lk.ring, lk.roff);
-        ring.Xd[1] = ring_ld(lk.ring, lk.roff + kRingPlaneBytes);
-        ring.Em[1] = ring_ld(lk.ring, lk.roff + 2u * kRingPlaneBytes);
-        *(lds_uint volatile *)lk.flag_mine = 1u;
-        lk.roff = 2u * kRLanes * 4u; // row 1 reads row 2's slot
+        lk.seen = ring_wait(lk, need0);
+        ring.Xm[1] = ring_ld(lk, off, 0); // row 1
+        ring.Xd[1] = ring_ld(lk, off, 1);
+        ring.Em[1] = ring_ld(lk, off, 2);
+        compiler_fence();
+        ring_publish(lk, off, 1u);
     }
     else
     {
-        lk.roff = 1u * kRLanes * 4u; // a producer's row 1 writes slot 1
         lk.seen = 0u;
 #pragma unroll
         for (int r = 0; r < D; ++r) // rows 1..D -> slots 1..D (mod 5)
@@ -586,22 +667,19 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     {                                                                                      \
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
-        if constexpr (!FIRST && IN == IO_LDS)                                               \
-        {   /* this row prefetches ring row j+1: the producer must have written it */       \
-            unsigned const need = pos < Lwave ? pos : Lwave;                                \
-            if (lk.seen < need) lk.seen = ring_wait(lk.flag_peer, need);                   \
-        }                                                                                  \
-        if constexpr (!LAST && OUT == IO_LDS)                                               \
-        {   /* this row writes slot j % kRD: the consumer must have taken row j - kRD */    \
-            if (j > lk.seen + kRD) lk.seen = ring_wait(lk.flag_peer, j - kRD);             \
-        }                                                                                  \
-        ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm, \
+        ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT, TBASE>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm, \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
-                                   dirty, o, lk, j QL_DIAG4_ARGS);                         \
-        if constexpr ((!FIRST && IN == IO_LDS) || (!LAST && OUT == IO_LDS))                 \
-            lk.roff = (lk.roff + kRLanes * 4u) & (kRingPlaneBytes - 1u);                   \
+                                   dirty, o, lk, j, gm QL_DIAG4_ARGS);                     \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
-        wq[(PH + kWD) % 5] = ld_u32(wordsT + ((pos + kWD) >> 4) * (unsigned)NT, tid4); /* row j + kWD */ \
+        {   /* row j + kWD.  The row pointer is wave-uniform: pinning it to SGPRs makes the load     */ \
+            /* "SGPR base + lane offset"; left alone, the compiler hoists wordsT + lane into a 64-bit */ \
+            /* VGPR pair and adds the row offset with a 64-bit VALU add every row                     */ \
+            gu32_ptr wrow = (gu32_ptr)wordsT + ((pos + kWD) >> 4) * (unsigned)NT;                \
+            asm volatile("" : "+s"(wrow));                                                       \
+            /* lane offset re-derived from `off` each row: a loop-invariant one would be widened */ \
+            /* to 64 bits outside the loop and the SGPR-base addressing mode would be lost       */ \
+            wq[(PH + kWD) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & (kRLanes * 4u - 1u)));     \
+        }                                                                                        \
         off += rowstep * 4u;                                                                     \
         QL_DIAG4_STEP                                                                            \
         ++j;                                                                               \
@@ -610,10 +688,28 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         /* mask 6: VALU / SALU arithmetic may still move across (+0.3 %)            */     \
         __builtin_amdgcn_sched_barrier(6);                                                 \
     }
+    // Ring hand-shake once per group of rows, not per row: the five-row body stays one basic block.
+    // A consumer row j prefetches ring row j+1, so a group starting at j needs rows <= j + n written; a
+    // producer group writes rows j .. j+n-1, whose slots must have been taken (row - kRD).  A side that
+    // has to wait waits for kRingHyst rows more than it needs, so that it polls once per burst.
+    auto ring_sync = [&](unsigned n) {
+        if constexpr (!FIRST && IN == IO_LDS)
+        {
+            unsigned const need = j + n < Lwave ? j + n : Lwave;
+            if (lk.seen < need) lk.seen = ring_wait(lk, need + kRingHyst < Lwave ? need + kRingHyst : Lwave);
+        }
+        if constexpr (!LAST && OUT == IO_LDS)
+        {
+            unsigned const last = j + n - 1u;
+            if (last > lk.seen + kRD) lk.seen = ring_wait(lk, last - kRD + kRingHyst);
+        }
+    };
     while (j + 4 <= Lwave)
     {
+        ring_sync(5u);
         QL_ROW(1) QL_ROW(2) QL_ROW(3) QL_ROW(4) QL_ROW(0)
     }
+    ring_sync(4u);
     if (j <= Lwave) QL_ROW(1)
     if (j <= Lwave) QL_ROW(2)
     if (j <= Lwave) QL_ROW(3)
@@ -759,32 +855,35 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     constexpr int NT = (int)kRLanes; // lanes per stage
     constexpr int KT = 4 * G;
     constexpr int TAB_FLOATS = G * NC * 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[]; // dcp_qlane2_lds_bytes()
-    __shared__ unsigned s_task;
-    unsigned const tid = threadIdx.x & (unsigned)(NT - 1); // lane within the stage = query slot of the block
-    unsigned const stage = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    float *const tabM = lds + stage * TAB_FLOATS;
-    float2 *const tabIN = reinterpret_cast<float2 *>(lds + 2 * TAB_FLOATS); // [code] = {insert, background}
-    float *const ringf = lds + 2 * TAB_FLOATS + 2 * NC;
-    unsigned *const flagP = reinterpret_cast<unsigned *>(ringf + 3 * kRD * NT); // producer (stage 0) rows written
-    unsigned *const flagC = flagP + NT;                                       // consumer (stage 1) rows taken
-    float *const rnull = reinterpret_cast<float *>(flagC + NT);               // null score: stage 0 -> final stage
+    __shared__ __attribute__((aligned(16))) float lds[kL2Bytes / 4u]; // the kernel's only LDS object: at address 0
+    // Stage 0 = wavefronts 0-3, stage 1 = wavefronts 4-7; wavefront w of stage 1 holds the same 64 queries as
+    // wavefront w of stage 0.  (The other map -- even / odd wavefronts -- measured 0.6 % slower.)
+    unsigned const wv = threadIdx.x >> 6;
+#if DCP_Q2_STAGEMAP == 0
+    unsigned const stage = __builtin_amdgcn_readfirstlane(wv & 1u);
+    unsigned const tid = ((wv >> 1) << 6) | (threadIdx.x & 63u); // lane within the stage = query slot of the block
+#else
+    unsigned const stage = __builtin_amdgcn_readfirstlane(wv >> 2);
+    unsigned const tid = threadIdx.x & 255u;
+#endif
+    float *const rnull = lds + kL2Null / 4u;
+    unsigned *const s_task_p = reinterpret_cast<unsigned *>(lds + kL2Task / 4u);
+    float2 *const tabIN = reinterpret_cast<float2 *>(lds + kL2TabIN / 4u); // [code] = {insert, background}
+    float *const tabM = lds + (stage ? kL2Tab1 / 4u : 0u);
     size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane;
-    unsigned const wave_lane0 = tid & ~63u;
 
     LdsLink lk;
-    lk.ring = (lds_float *)(ringf + tid);
-    lk.flag_mine = (lds_uint *)((stage == 0u ? flagP : flagC) + tid);
-    lk.flag_peer = (lds_uint *)((stage == 0u ? flagC : flagP) + wave_lane0);
-    lk.roff = 0u;
+    lk.base = (lds_char *)lds;
+    lk.my_flag = stage == 0u ? kL2FlagP : kL2FlagC;
+    lk.peer_flag = (stage == 0u ? kL2FlagC : kL2FlagP) + (tid & ~63u) * 4u;
     lk.seen = 0u;
 
     for (;;)
     {
-        if (threadIdx.x == 0) s_task = atomicAdd(a.task_counter, 1u);
+        if (threadIdx.x == 0) *s_task_p = atomicAdd(a.task_counter, 1u);
         __syncthreads();
-        unsigned const task = __builtin_amdgcn_readfirstlane(s_task);
+        unsigned const task = __builtin_amdgcn_readfirstlane(*s_task_p);
         __syncthreads();
         if (task >= a.ntasks) break;
         unsigned const slot = a.nprof - 1u - task / a.nqblocks; // biggest profiles first
@@ -829,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
                 for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
                     dst[i] = src[i];
             }
-            *(lds_uint volatile *)lk.flag_mine = 0u; // row counters restart with every step
+            flag_store((lds_uint *)(lk.base + lk.my_flag + tid * 4u), 0u); // row counters restart with every step
             __syncthreads();
             if (Lwave == 0u || !mine) continue;
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
@@ -837,20 +936,21 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
 #if DCP_QLANE_DIAG & 4
 #error "the two-stage kernel has no DIAG=4 build"
 #endif
-#define QL2_SWEEP(F, L_, IN_, OUT_)                                                                       \
-    ql_sweep<G, F, L_, NT, D, IN_, OUT_>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
+#define QL2_SWEEP(F, L_, IN_, OUT_, TB_)                                                                  \
+    ql_sweep<G, F, L_, NT, D, IN_, OUT_, TB_>(tt, lds, reinterpret_cast<float2 const *>(lds + (kL2TabIN - TB_ / 2u) / 4u), \
+                                              wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
             if (stage == 0u)
             {
-                if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM);
-                else if (first) QL2_SWEEP(true, false, IO_HBM, IO_LDS);
-                else if (last) QL2_SWEEP(false, true, IO_HBM, IO_HBM);
-                else QL2_SWEEP(false, false, IO_HBM, IO_LDS);
+                if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM, 0u);
+                else if (first) QL2_SWEEP(true, false, IO_HBM, IO_LDS, 0u);
+                else if (last) QL2_SWEEP(false, true, IO_HBM, IO_HBM, 0u);
+                else QL2_SWEEP(false, false, IO_HBM, IO_LDS, 0u);
                 if (first) rnull[tid] = o.Rn;
             }
             else
             {
-                if (last) QL2_SWEEP(false, true, IO_LDS, IO_HBM);
-                else QL2_SWEEP(false, false, IO_LDS, IO_HBM);
+                if (last) QL2_SWEEP(false, true, IO_LDS, IO_HBM, kL2Tab1);
+                else QL2_SWEEP(false, false, IO_LDS, IO_HBM, kL2Tab1);
             }
 #undef QL2_SWEEP
         }
@@ -925,24 +1025,11 @@ extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream
                        (hipStream_t)stream, *a);
 }
 
-extern "C" unsigned dcp_qlane2_lds_bytes(void)
-{
-    // two tile images, the insert/background table, the ring's three planes, two flag arrays, the null scores
-    return (unsigned)(sizeof(float) * (2u * 2u * NC * 4u + 2u * NC + 3u * kRD * kRLanes + 3u * kRLanes));
-}
+extern "C" unsigned dcp_qlane2_lds_bytes(void) { return kL2Bytes; }
 
 extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    auto kern = viterbi_qlane2_kernel<2, DCP_QLANE_D>;
-    static bool configured = false;
-    unsigned const lds = dcp_qlane2_lds_bytes();
-    if (!configured)
-    {
-        if (hipFuncSetAttribute((void const *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return 1;
-        configured = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL((viterbi_qlane2_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, *a);
     return 0;
 }
 

@@ -12,13 +12,14 @@ with ThreadPoolExecutor(16) as ex:
 sc = dcp.Scanner(0)
 sc.upload_db(profs)
 del profs
-q = bench.make_queries(0, 256, 1000)
-off = (np.arange(257, dtype=np.uint64) * 1000).astype(np.uint32)
+q = bench.make_queries(0, 1024, 1000)
+off = (np.arange(1025, dtype=np.uint64) * 1000).astype(np.uint32)
 sc.upload_seqs_flat(q.reshape(-1), off)
 cellsM = int(sizes.sum())
-for kname, kern in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE)):
-    for nq in (1, 2, 4, 16, 32, 48, 64, 96, 128, 256):
-        if kname == "rowsweep" and nq > 64 or kname == "qlane" and nq < 16:
+for kname, kern in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE),
+                    ("qlane2", dcp.KERNEL_QLANE2)):
+    for nq in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 256, 512, 1024):
+        if kname == "rowsweep" and nq > 64 or kname.startswith("qlane") and nq < 16:
             continue
         for rep in range(2):
             t = time.perf_counter()
