@@ -794,6 +794,11 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             kernel = t_ql < t_rs ? 2 : 1;
             // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
             if (lmax > 200000u) kernel = 1;
+            // The two-stage variant (512-thread blocks, two tiles of a profile in flight) wins once the
+            // query blocks are mostly full -- measured on the C3 DB (profiles/r02/latency_probe.txt):
+            // 256 queries 664 vs 696 ms, 1024 queries 2600 vs 2724 ms; below that its idle wavefronts
+            // still sit through every barrier (128 queries 586 vs 517 ms).
+            if (kernel == 2 && nq >= 192u) kernel = 3;
         }
     }
     if (kernel < 1 || kernel > 3) return c->fail(DCP_EINVAL, "unknown kernel %d", kernel);
