@@ -396,7 +396,7 @@ def main():
         dom_algo_bytes = dom["bytes"] / dom["launches"]
         is_qlane = not dom_key[1]
         kname = (f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>" if dom_key[1] else
-                 f"viterbi_qlane_kernel<KT={dom_key[0]}>")
+                 f"viterbi_qlane{'2' if sc.last_scan_kernel == dcp.KERNEL_QLANE2 else ''}_kernel<KT={dom_key[0]}>")
         # What binds the dominant kernel: VALU ISSUE.  28 max/add lane-ops per cell
         # (11 for M_k, 10 for I_k, 3 for D_k, 4 for E/B) against the chip's f32 VALU rate:
         # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s (= 157.3 TFLOPS / 2: max and
@@ -425,7 +425,9 @@ def main():
         #   compulsory: SURVEY 8d note 2 -- 548*M + L + 8 bytes per pair (compact profile streamed once)
         ntiles = (sizes[b:e].astype(np.int64) + 7) // 8
         lanes = ((qstep // world + 63) // 64) * 64 if qlen else None
-        scratch_bytes = (int(24 * int((ntiles - 1).sum()) * lanes * qlen) if (is_qlane and qlen) else None)
+        two_stage = sc.last_scan_kernel == dcp.KERNEL_QLANE2
+        hbm_boundaries = ((ntiles - 1) // 2) if two_stage else (ntiles - 1)  # odd -> even only / every boundary
+        scratch_bytes = (int(24 * int(hbm_boundaries.sum()) * lanes * qlen) if (is_qlane and qlen) else None)
         tile_bytes = (int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep // world + 255) // 256) if is_qlane else None)
         npairs_launch = (e - b) * (qstep // world)
         compulsory = int(548 * int(sizes[b:e].sum()) * (qstep // world) + (qlen + 8) * npairs_launch) if qlen else None

@@ -107,6 +107,7 @@ struct dcp_gpu_ctx
     unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
     unsigned num_cus = 0;
     int last_kernel = 0; // 1 row sweep, 2 query lane
+    int last_kernel_variant = 0; // as dcp_scan_params.kernel names it: 1, 2 or 3 (two-stage query lane)
     unsigned redo_cap_limit = 1u << 26; // dcp_gpu_test_set_redo_cap
     float last_ql_ms = 0;
 
@@ -803,6 +804,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     }
     if (kernel < 1 || kernel > 3) return c->fail(DCP_EINVAL, "unknown kernel %d", kernel);
     bool const two_stage = kernel == 3; // the query-lane kernel's two-stage variant (dcp_qlane.hip)
+    c->last_kernel_variant = kernel;
     if (two_stage) kernel = 2;
     c->last_kernel = kernel;
     if (kernel == 2)
@@ -1051,6 +1053,7 @@ float dcp_gpu_last_scan_ms(dcp_gpu_ctx *c)
 }
 
 unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *c) { return c ? c->last_launches : 0; }
+int dcp_gpu_last_scan_kernel(dcp_gpu_ctx const *c) { return c && c->scanned ? c->last_kernel_variant : 0; }
 
 int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_info *out)
 {

@@ -312,6 +312,9 @@ float dcp_gpu_last_scan_ms(dcp_gpu_ctx *);
 /* Number of DP kernel launches of the last scan (row sweep: one per profile
  * size class; query lane: one, plus one redo launch per size class). */
 unsigned dcp_gpu_last_scan_launches(dcp_gpu_ctx const *);
+/* The kernel the last scan ran with, as dcp_scan_params.kernel names it (1, 2 or 3): what the cost
+ * model chose when the scan asked for 0.  0 before any scan. */
+int dcp_gpu_last_scan_kernel(dcp_gpu_ctx const *);
 /* Launch i of the last scan: its kernel shape, HIP-event duration on the
  * context's stream, DP cells and algorithmic bytes.  The cells
  * of a query-lane scan are all counted in its launch 0; its redo launches

@@ -17,15 +17,24 @@ cd /tmp
 run() { # name, rocprof options...
     local name=$1; shift
     echo "== pass $name: $*"
-    timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o run -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"
+    timeout -k 10 ${PASS_TIMEOUT:-400} rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o run -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"
     tail -c 300 "$OUT/$name.json"; echo
 }
-run stats --kernel-trace --stats
-run pmc_fetch --pmc FETCH_SIZE
-run pmc_write --pmc WRITE_SIZE
-run pmc_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
-run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM
+# PASSES selects a subset (default: all five), so that a long command fits gpurun's time limit in two calls:
+#   PASSES="stats fetch write" ... ; PASSES="sq lds" ...   (same TAG: the summary folds what is there)
+PASSES=${PASSES:-stats fetch write sq lds}
+for p in $PASSES; do
+  case $p in
+    stats) run stats --kernel-trace --stats ;;
+    fetch) run pmc_fetch --pmc FETCH_SIZE ;;
+    write) run pmc_write --pmc WRITE_SIZE ;;
+    sq)    run pmc_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE ;;
+    lds)   run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM ;;
+  esac
+done
 cd "$ROOT"
-python3 profiles/pmc_summary.py "$OUT/pmc.json" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_lds" > "$OUT/pmc_derived.txt"
-cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
-cat "$OUT/pmc_derived.txt"
+DIRS=""
+for d in pmc_fetch pmc_write pmc_sq pmc_lds; do [ -d "$OUT/$d" ] && DIRS="$DIRS $OUT/$d"; done
+[ -n "$DIRS" ] && python3 profiles/pmc_summary.py "$OUT/pmc.json" $DIRS > "$OUT/pmc_derived.txt" && cat "$OUT/pmc_derived.txt"
+[ -d "$OUT/stats" ] && cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
+true
