@@ -107,6 +107,8 @@ struct dcp_gpu_ctx
     unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
     unsigned num_cus = 0;
     int last_kernel = 0; // 1 row sweep, 2 query lane
+    unsigned ql_occ[3] = {0, 0, 0}; // blocks per CU of the 64-, 128- and 256-query single-stage kernel
+    unsigned qorder_nt = 0;         // block size the cached query order / transposed words were built for
     int last_kernel_variant = 0; // as dcp_scan_params.kernel names it: 1, 2 or 3 (two-stage query lane)
     unsigned redo_cap_limit = 1u << 26; // dcp_gpu_test_set_redo_cap
     float last_ql_ms = 0;
@@ -203,6 +205,9 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         hipDeviceProp_t prop;
         c->num_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? (unsigned)prop.multiProcessorCount : 256u;
         c->ql_G = (int)dcp_qlane_tile_nodes() / 4;
+        c->ql_occ[0] = dcp_qlane_blocks_per_cu(64);
+        c->ql_occ[1] = dcp_qlane_blocks_per_cu(128);
+        c->ql_occ[2] = std::max(1u, dcp_qlane_blocks_per_cu(dcp_qlane_block_size()));
     }
     bool ok = true;
     for (int k = 0; k <= kNumClasses; ++k)
@@ -763,6 +768,11 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->last_q0 = q_begin;
     c->last_q1 = q_end;
 
+    // Queries per block of the single-stage query-lane kernel: narrow blocks for small batches when three
+    // of them fit a CU (dcp_qlane_blocks_per_cu), else the standard 256.
+    unsigned ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = c->ql_occ[2];
+    if (nq <= 64u && c->ql_occ[0] > c->ql_occ[2]) ql_nt = 64u, ql_blocks_per_cu = c->ql_occ[0];
+    else if (nq <= 128u && c->ql_occ[1] > c->ql_occ[2]) ql_nt = 128u, ql_blocks_per_cu = c->ql_occ[1];
     // kernel choice: the query-lane kernel needs enough queries to fill its lanes
     int kernel = prm->kernel;
     if (kernel == 0)
@@ -775,7 +785,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             //                takes 0.52 us with one busy wavefront, 0.73 us with four.
             // On the 20k-profile DB the switch comes at 45 queries; a DB of a few hundred profiles
             // stays with the row sweep up to several hundred queries (its tasks cannot fill the grid).
-            unsigned const NTq = dcp_qlane_block_size();
+            unsigned const NTq = ql_nt;
             std::vector<unsigned> len(c->seq_len.begin() + q_begin, c->seq_len.begin() + q_end);
             std::sort(len.begin(), len.end());
             double sum_len = 0, sum_block_lmax = 0;
@@ -788,7 +798,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             double const t_rs = std::max((double)c->sum_core * sum_len / 340e9, lmax * 1.6e-6); // or one pair's row chain
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
             double const trow = (0.52 + 0.07 * (waves - 1u)) * 1e-6;
-            double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, 2ull * c->num_cus);
+            double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
             double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
                                          (double)c->sum_tiles * sum_block_lmax * trow / resident) +
                                 1e-4; // its redo launches
@@ -807,10 +817,11 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->last_kernel_variant = kernel;
     if (two_stage) kernel = 2;
     c->last_kernel = kernel;
+    if (two_stage) ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = 1; // 2 x 256 queries' wavefronts, one block per CU
     if (kernel == 2)
     {
         // queries sorted by length so that the lanes of a block finish together
-        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end)
+        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt)
         {
             std::vector<uint32_t> ord(nq);
             for (unsigned i = 0; i < nq; ++i)
@@ -824,7 +835,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
             HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             // per block of NT queries: (longest member / 16 + 3) word rows, transposed
-            unsigned const NTq = dcp_qlane_block_size();
+            unsigned const NTq = ql_nt;
             unsigned const nqb = (nq + NTq - 1u) / NTq;
             std::vector<uint32_t> wt_off(nqb + 1u, 0u);
             uint64_t tot = 0;
@@ -842,10 +853,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
             ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
             ta.nseqs = nq, ta.nqblocks = nqb;
-            dcp_launch_qlane_transpose(&ta, c->stream);
+            if (dcp_launch_qlane_transpose(&ta, NTq, c->stream)) return c->fail(DCP_EFAIL, "no kernel for %u-query blocks", NTq);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(c->stream)); // ord / wt_off are stack-local
-            c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax;
+            c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax, c->qorder_nt = NTq;
         }
         if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
     }
@@ -880,7 +891,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.nseqs = nq;
         qa.q_base = q_begin;
         qa.lmax = c->qorder_lmax;
-        unsigned const NT = dcp_qlane_block_size();
+        unsigned const NT = ql_nt;
         qa.nqblocks = (nq + NT - 1u) / NT;
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
@@ -924,7 +935,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
         uint64_t fit = per_block ? budget / per_block : 0;
         // one 512-thread block per CU (two-stage) or two 256-thread blocks (single-stage)
-        uint64_t const resident_blocks = two_stage ? (uint64_t)c->num_cus : 2ull * c->num_cus;
+        uint64_t const resident_blocks = (uint64_t)ql_blocks_per_cu * c->num_cus;
         unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, resident_blocks), fit);
         if (nblocks == 0)
             return c->fail(DCP_ENOMEM, "sequence of %u nt is too long for the query-lane kernel: use kernel = 1", qa.lmax);
@@ -933,7 +944,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-        if (two_stage ? dcp_launch_qlane2(&qa, nblocks, c->stream) : dcp_launch_qlane(&qa, nblocks, c->stream))
+        if (two_stage ? dcp_launch_qlane2(&qa, nblocks, c->stream) : dcp_launch_qlane(&qa, nblocks, NT, c->stream))
             return c->fail(DCP_EFAIL, "query-lane launch failed");
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));

@@ -161,11 +161,12 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
-int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream);
+int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream); // nt: 64, 128 or 256 queries per block
 // two-stage variant: 512-thread blocks, one per CU; != 0 if the kernel cannot be configured
 int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream);
 unsigned dcp_qlane2_lds_bytes(void);
-void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream);
+int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream);
+unsigned dcp_qlane_blocks_per_cu(unsigned nt);
 void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);

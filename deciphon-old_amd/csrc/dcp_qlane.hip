@@ -145,10 +145,6 @@ __device__ __forceinline__ float ld_off(float const *base, unsigned boff)
 }
 typedef uint32_t const __attribute__((address_space(1))) *gu32_ptr; // explicitly global: survives an asm pin
 typedef char const __attribute__((address_space(1))) *gchar_ptr;
-__device__ __forceinline__ unsigned ld_u32(uint32_t const *base, unsigned boff)
-{
-    return *reinterpret_cast<uint32_t const *>(reinterpret_cast<char const *>(base) + boff);
-}
 __device__ __forceinline__ void st_off(float *base, unsigned boff, float v)
 {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + boff) = v;
@@ -678,7 +674,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
             asm volatile("" : "+s"(wrow));                                                       \
             /* lane offset re-derived from `off` each row: a loop-invariant one would be widened */ \
             /* to 64 bits outside the loop and the SGPR-base addressing mode would be lost       */ \
-            wq[(PH + kWD) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & (kRLanes * 4u - 1u)));     \
+            wq[(PH + kWD) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & ((unsigned)NT * 4u - 1u))); \
         }                                                                                        \
         off += rowstep * 4u;                                                                     \
         QL_DIAG4_STEP                                                                            \
@@ -731,7 +727,7 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 } // namespace
 
 template <int G, int NT, int D>
-__global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_args a)
+__global__ __launch_bounds__(NT, (NT >= 128 ? 2 : 1)) void viterbi_qlane_kernel(dcp_qlane_args a)
 {
     constexpr int KT = 4 * G;
     constexpr int TAB_FLOATS = G * NC * 4;
@@ -1015,14 +1011,31 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 #define DCP_QLANE_D 3 // rows of boundary prefetch (1..5); measured 1: -30 %, 2: -1 %, 3: best, 4: -0.3 %, 5: -0.7 %
 #endif
 extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
+// Narrow blocks for small batches: with <= 64 (128) queries a 256-thread block has one (two) busy
+// wavefronts and the CU's LDS holds two blocks; 64- and 128-thread blocks of the same kernel need the
+// same 54.5 KB each, and three of them fit a CU: three (six) busy wavefronts instead of two (four).
+// Returns the blocks of `nt` threads one CU holds (0 if nt is not built).
+extern "C" unsigned dcp_qlane_blocks_per_cu(unsigned nt)
+{
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (nt == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, 64, DCP_QLANE_D>, 64, 0);
+    else if (nt == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, 128, DCP_QLANE_D>, 128, 0);
+    else if (nt == DCP_QLANE_NT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, DCP_QLANE_NT, DCP_QLANE_D>, DCP_QLANE_NT, 0);
+    return e == hipSuccess && n > 0 ? (unsigned)n : 0u;
+}
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
 
-extern "C" void dcp_launch_qlane_transpose(dcp_qlane_args const *a, void *stream)
+extern "C" int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream)
 {
-    hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0,
-                       (hipStream_t)stream, *a);
+    if (nt == 64) hipLaunchKernelGGL((transpose_words_kernel<64>), dim3(a->nqblocks), dim3(64), 0, (hipStream_t)stream, *a);
+    else if (nt == 128) hipLaunchKernelGGL((transpose_words_kernel<128>), dim3(a->nqblocks), dim3(128), 0, (hipStream_t)stream, *a);
+    else if (nt == DCP_QLANE_NT)
+        hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0, (hipStream_t)stream, *a);
+    else return 1;
+    return 0;
 }
 
 extern "C" unsigned dcp_qlane2_lds_bytes(void) { return kL2Bytes; }
@@ -1033,8 +1046,11 @@ extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void
     return 0;
 }
 
-extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, void *stream)
+extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream)
 {
-    launch_ql<2, DCP_QLANE_NT, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
+    if (nt == 64) launch_ql<2, 64, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
+    else if (nt == 128) launch_ql<2, 128, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
+    else if (nt == DCP_QLANE_NT) launch_ql<2, DCP_QLANE_NT, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
+    else return 1;
     return 0;
 }

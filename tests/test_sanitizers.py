@@ -56,3 +56,25 @@ def test_file_parsers_survive_mutation_fuzzing_under_asan_ubsan(dcp, tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fuzz_parsers ok" in r.stdout
+
+
+def test_dcp_database_path_survives_mutation_fuzzing_under_asan_ubsan(dcp, tmp_path):
+    """tests/c/fuzz_dcp.c: thousands of mutated .dcp files (byte edits, truncations, duplicated and deleted
+    runs, blown-up length fields, bit flips) through protein_db_reader_open + profile_reader_setup(_balanced)
+    + profile_reader_next, the host layer's own C files built with ASan + UBSan + leak check: every file ends
+    in RC_END or a clean error code."""
+    import glob
+    host = sorted(glob.glob(os.path.join(ROOT, "deciphon-old_amd", "host", "*.c")))
+    exe = str(tmp_path / "fuzz_dcp")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "fuzz_dcp.c")] + host +
+                          ["-o", exe, "-L", os.path.join(ROOT, "deciphon-old_amd"), "-ldcp_hip", "-lm", "-fopenmp",
+                           "-Wl,-rpath," + os.path.join(ROOT, "deciphon-old_amd")])
+    log = str(tmp_path / "asan")
+    env = dict(os.environ, ASAN_OPTIONS=f"detect_leaks=1:log_path={log}")
+    r = subprocess.run([exe, str(tmp_path / "fuzz.dcp"), "6000", "20261004"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    reports = [f for f in os.listdir(tmp_path) if f.startswith("asan")]
+    assert r.returncode == 0 and not reports, r.stdout + "".join(open(os.path.join(tmp_path, f)).read()[-2000:] for f in reports)
+    assert "fuzz_dcp ok" in r.stdout
