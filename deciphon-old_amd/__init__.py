@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "dcp_gpu_ctx_new", "dcp_gpu_ctx_del", "dcp_gpu_last_error", "dcp_gpu_stream",
     "dcp_gpu_db_upload", "dcp_gpu_db_nprofiles", "dcp_gpu_db_fetch_match_table",
     "dcp_gpu_seqs_upload", "dcp_gpu_seqs_upload_text", "dcp_gpu_nseqs", "dcp_gpu_scan",
-    "dcp_gpu_sync", "dcp_gpu_test_set_redo_cap", "dcp_gpu_last_scan_kernel", "dcp_gpu_last_scan_redo_pairs", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
+    "dcp_gpu_sync", "dcp_gpu_test_set_redo_cap", "dcp_gpu_last_scan_kernel", "dcp_gpu_hit_buffer", "dcp_gpu_last_scan_redo_pairs", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
     "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
     "dcp_gpu_last_scan_launch_info", "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
     "dcp_gpu_trace_paths", "dcp_state_name", "dcp_profile_decode", "dcp_gc_decode",

@@ -705,6 +705,16 @@ int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *c, void *hits_dev, unsigned cap, void *n
     return DCP_OK;
 }
 
+int dcp_gpu_hit_buffer(dcp_gpu_ctx *c, void **hits_dev, void **nhits_dev, unsigned *cap)
+{
+    if (!c || !hits_dev || !nhits_dev || !cap) return DCP_EINVAL;
+    if (!c->scanned) return c->fail(DCP_EINVAL, "no scan yet");
+    *hits_dev = c->ext_hits ? (void *)c->ext_hits : (void *)c->d_hits.p;
+    *nhits_dev = c->ext_hits ? (void *)c->ext_nhits : (void *)c->d_nhits.p;
+    *cap = c->ext_hits ? c->ext_cap : c->hit_cap;
+    return DCP_OK;
+}
+
 int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsigned q_begin,
                        unsigned q_end)
 {

@@ -293,6 +293,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *, struct dcp_scan_params const *,
  * buffer. */
 int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *, void *hits_dev, unsigned cap,
                            void *nhits_dev);
+/* The device memory the last scan wrote its hit records and counter to (the context's own buffer, or the
+ * caller's from dcp_gpu_set_hit_buffer) -- what a C host hands to dcp_dist_gather_hits without touching
+ * the HIP API itself.  Call dcp_gpu_sync first: a query-lane scan completes its redo pairs there. */
+int dcp_gpu_hit_buffer(dcp_gpu_ctx *, void **hits_dev, void **nhits_dev, unsigned *cap);
 /* TEST-ONLY: shrink the per-size-class capacity of the redo lists (default 2^26 pairs; 0 restores
  * it) so a test can reach the overflow path.  Results are unaffected: an overflowed scan is
  * repeated with the row-sweep kernel. */

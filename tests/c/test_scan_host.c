@@ -458,6 +458,80 @@ static void scan_run_batched(void)
     fclose(fp);
 }
 
+/* One process per GPU, in C: shard map, communicator through the file rendezvous, scan, RCCL gather.
+ * One rank is all a single-GPU box allows (RCCL refuses two ranks on one device); it still runs
+ * dlopen(librccl), ncclCommInitRank, the counts all-gather, the local leg of the gather-v and the merge. */
+static void one_process_per_gpu(void)
+{
+    enum { NP = 6 };
+    unsigned const sizes[NP] = {40, 25, 70, 33, 90, 12};
+    unsigned b = 9, e = 9;
+    dcp_dist_shard(sizes, NP, 1, 0, &b, &e);
+    CHECK(b == 0 && e == NP);
+    dcp_dist_shard(sizes, NP, 3, 1, &b, &e);
+    CHECK(b >= 1 && e > b && e < NP); /* the middle rank of three */
+
+    char idfile[64];
+    snprintf(idfile, sizeof idfile, "/tmp/dcp_dist_id_XXXXXX");
+    int fd = mkstemp(idfile);
+    CHECK(fd >= 0);
+    close(fd);
+    remove(idfile); /* rank 0 creates it */
+    dcp_dist *comm = dcp_dist_init_from_file(idfile, 0, 1, 0, 10.0);
+    CHECK(comm != NULL);
+    if (!comm) return;
+    CHECK(dcp_dist_rank(comm) == 0 && dcp_dist_nranks(comm) == 1);
+
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, imm_super(&imm_dna_iupac));
+    dcp_profile *impls[NP];
+    char domain[NP][3 * 90 + 1];
+    for (unsigned p = 0; p < NP; ++p)
+    {
+        struct protein_profile prof;
+        char acc[16];
+        snprintf(acc, sizeof acc, "PF%05u", p);
+        peaked_profile(&prof, &code, acc, sizes[p], p, domain[p]);
+        impls[p] = prof.impl;
+        prof.impl = NULL; /* moved out */
+        profile_del(&prof.super);
+    }
+    dcp_gpu_ctx *ctx = dcp_gpu_ctx_new(0);
+    CHECK(ctx != NULL);
+    CHECK(dcp_gpu_db_upload(ctx, impls, NP, 0) == DCP_OK);
+    char text[1024];
+    uint32_t off[4] = {0, 0, 0, 0};
+    int n = snprintf(text, sizeof text, "ACGTTGCAAGGCTTAACC%sGGTTACG", domain[2]);
+    off[1] = (uint32_t)n;
+    n += snprintf(text + n, sizeof text - (size_t)n, "TTGACCAGGGCATCATCAGGACCCGTA");
+    off[2] = (uint32_t)n;
+    n += snprintf(text + n, sizeof text - (size_t)n, "GATTACA%sTGCATGCAAT", domain[4]);
+    off[3] = (uint32_t)n;
+    CHECK(dcp_gpu_seqs_upload_text(ctx, text, off, 3) == DCP_OK);
+    struct dcp_scan_params prm = {1, 0, 10.0f, 0, 0};
+    CHECK(dcp_gpu_scan(ctx, &prm) == DCP_OK && dcp_gpu_sync(ctx) == DCP_OK);
+    struct dcp_hit want[64];
+    unsigned nwant = 0;
+    CHECK(dcp_gpu_fetch_hits(ctx, want, 64, &nwant) == DCP_OK && nwant >= 2);
+    void *hits_dev = NULL, *nhits_dev = NULL;
+    unsigned cap = 0;
+    CHECK(dcp_gpu_hit_buffer(ctx, &hits_dev, &nhits_dev, &cap) == DCP_OK && hits_dev && nhits_dev && cap >= nwant);
+    struct dcp_hit *all = NULL;
+    unsigned nall = 0;
+    CHECK(dcp_dist_gather_hits(comm, hits_dev, nhits_dev, cap, 100 /* shard starts at profile 100 */, 0,
+                               dcp_gpu_stream(ctx), &all, &nall) == DCP_OK);
+    CHECK(nall == nwant && all != NULL);
+    for (unsigned h = 0; all && h < nall && h < nwant; ++h)
+        CHECK(all[h].seq_idx == want[h].seq_idx && all[h].profile_idx == want[h].profile_idx + 100 &&
+              all[h].alt_loglik == want[h].alt_loglik && all[h].null_loglik == want[h].null_loglik);
+    dcp_dist_free_hits(all);
+    dcp_gpu_ctx_del(ctx);
+    for (unsigned p = 0; p < NP; ++p)
+        dcp_profile_del(impls[p]);
+    dcp_dist_free(comm);
+    remove(idfile);
+}
+
 /* test/standard_profile.c:5-31 is a smoke test (no numeric golden): a standard profile is a typed
  * shell around two imm_dp, and the scan path never takes one (profile_reader.c:95-98) */
 static void standard_profile_shell(void)
@@ -496,6 +570,7 @@ int main(void)
     scan_threads();
     scan_run_batched();
     remove(g_db_path);
+    one_process_per_gpu();
     CHECK(xmath_partition_size(20000, 8, 7) == 2500);
     CHECK(fabsf(xmath_lrt(-48.927f, -54.355f) - (-10.856f)) < 1e-3f);
     if (failed) fprintf(stderr, "%d check(s) failed\n", failed);
