@@ -107,7 +107,6 @@ struct dcp_gpu_ctx
     unsigned qorder_q0 = ~0u, qorder_q1 = ~0u, qorder_lmax = 0;
     unsigned num_cus = 0;
     int last_kernel = 0; // 1 row sweep, 2 query lane
-    unsigned ql_occ[3] = {0, 0, 0}; // blocks per CU of the 64-, 128- and 256-query single-stage kernel
     unsigned qorder_nt = 0;         // block size the cached query order / transposed words were built for
     int last_kernel_variant = 0; // as dcp_scan_params.kernel names it: 1, 2 or 3 (two-stage query lane)
     unsigned redo_cap_limit = 1u << 26; // dcp_gpu_test_set_redo_cap
@@ -205,9 +204,6 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         hipDeviceProp_t prop;
         c->num_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? (unsigned)prop.multiProcessorCount : 256u;
         c->ql_G = (int)dcp_qlane_tile_nodes() / 4;
-        c->ql_occ[0] = dcp_qlane_blocks_per_cu(64);
-        c->ql_occ[1] = dcp_qlane_blocks_per_cu(128);
-        c->ql_occ[2] = std::max(1u, dcp_qlane_blocks_per_cu(dcp_qlane_block_size()));
     }
     bool ok = true;
     for (int k = 0; k <= kNumClasses; ++k)
@@ -778,11 +774,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->last_q0 = q_begin;
     c->last_q1 = q_end;
 
-    // Queries per block of the single-stage query-lane kernel: narrow blocks for small batches when three
-    // of them fit a CU (dcp_qlane_blocks_per_cu), else the standard 256.
-    unsigned ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = c->ql_occ[2];
-    if (nq <= 64u && c->ql_occ[0] > c->ql_occ[2]) ql_nt = 64u, ql_blocks_per_cu = c->ql_occ[0];
-    else if (nq <= 128u && c->ql_occ[1] > c->ql_occ[2]) ql_nt = 128u, ql_blocks_per_cu = c->ql_occ[1];
+    // Queries per block of the single-stage query-lane kernel.  (Narrow 64- / 128-query blocks were tried for
+    // small batches: hipOccupancyMaxActiveBlocksPerMultiprocessor reports three 54.5 KB blocks per CU, the
+    // measured rate is that of two -- profiles/r02/latency_probe_narrow_blocks_attempt.txt -- so they are gone.)
+    unsigned ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = 2; // 2 x 54.5 KB of LDS, 2 x 4 wavefronts of 256 VGPRs
     // kernel choice: the query-lane kernel needs enough queries to fill its lanes
     int kernel = prm->kernel;
     if (kernel == 0)

@@ -166,7 +166,6 @@ int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, voi
 int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream);
 unsigned dcp_qlane2_lds_bytes(void);
 int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream);
-unsigned dcp_qlane_blocks_per_cu(unsigned nt);
 void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);

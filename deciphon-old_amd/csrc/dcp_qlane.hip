@@ -182,6 +182,9 @@ constexpr unsigned kRingPlaneBytes = kRD * kRLanes * 4u;
 #ifndef DCP_Q2_SLEEP
 #define DCP_Q2_SLEEP 2
 #endif
+#ifndef DCP_Q2_PRIO
+#define DCP_Q2_PRIO 0 // 1: consumer stage at s_setprio 1; 2: producer stage
+#endif
 #ifndef DCP_Q2_STAGEMAP
 #define DCP_Q2_STAGEMAP 1 // 0: even / odd wavefronts; 1: wavefronts 0-3 / 4-7
 #endif
@@ -727,7 +730,7 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v)
 } // namespace
 
 template <int G, int NT, int D>
-__global__ __launch_bounds__(NT, (NT >= 128 ? 2 : 1)) void viterbi_qlane_kernel(dcp_qlane_args a)
+__global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_args a)
 {
     constexpr int KT = 4 * G;
     constexpr int TAB_FLOATS = G * NC * 4;
@@ -869,6 +872,11 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane;
 
+#if DCP_Q2_PRIO == 1
+    if (stage == 1u) __builtin_amdgcn_s_setprio(1);
+#elif DCP_Q2_PRIO == 2
+    if (stage == 0u) __builtin_amdgcn_s_setprio(1);
+#endif
     LdsLink lk;
     lk.base = (lds_char *)lds;
     lk.my_flag = stage == 0u ? kL2FlagP : kL2FlagC;
@@ -1011,28 +1019,13 @@ static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 #define DCP_QLANE_D 3 // rows of boundary prefetch (1..5); measured 1: -30 %, 2: -1 %, 3: best, 4: -0.3 %, 5: -0.7 %
 #endif
 extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
-// Narrow blocks for small batches: with <= 64 (128) queries a 256-thread block has one (two) busy
-// wavefronts and the CU's LDS holds two blocks; 64- and 128-thread blocks of the same kernel need the
-// same 54.5 KB each, and three of them fit a CU: three (six) busy wavefronts instead of two (four).
-// Returns the blocks of `nt` threads one CU holds (0 if nt is not built).
-extern "C" unsigned dcp_qlane_blocks_per_cu(unsigned nt)
-{
-    int n = 0;
-    hipError_t e = hipErrorInvalidValue;
-    if (nt == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, 64, DCP_QLANE_D>, 64, 0);
-    else if (nt == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, 128, DCP_QLANE_D>, 128, 0);
-    else if (nt == DCP_QLANE_NT) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, viterbi_qlane_kernel<2, DCP_QLANE_NT, DCP_QLANE_D>, DCP_QLANE_NT, 0);
-    return e == hipSuccess && n > 0 ? (unsigned)n : 0u;
-}
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
 
 extern "C" int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream)
 {
-    if (nt == 64) hipLaunchKernelGGL((transpose_words_kernel<64>), dim3(a->nqblocks), dim3(64), 0, (hipStream_t)stream, *a);
-    else if (nt == 128) hipLaunchKernelGGL((transpose_words_kernel<128>), dim3(a->nqblocks), dim3(128), 0, (hipStream_t)stream, *a);
-    else if (nt == DCP_QLANE_NT)
+    if (nt == DCP_QLANE_NT)
         hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0, (hipStream_t)stream, *a);
     else return 1;
     return 0;
@@ -1048,9 +1041,7 @@ extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void
 
 extern "C" int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream)
 {
-    if (nt == 64) launch_ql<2, 64, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
-    else if (nt == 128) launch_ql<2, 128, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
-    else if (nt == DCP_QLANE_NT) launch_ql<2, DCP_QLANE_NT, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
+    if (nt == DCP_QLANE_NT) launch_ql<2, DCP_QLANE_NT, DCP_QLANE_D>(a, nblocks, (hipStream_t)stream);
     else return 1;
     return 0;
 }
