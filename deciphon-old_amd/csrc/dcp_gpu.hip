@@ -778,6 +778,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     // small batches: hipOccupancyMaxActiveBlocksPerMultiprocessor reports three 54.5 KB blocks per CU, the
     // measured rate is that of two -- profiles/r02/latency_probe_narrow_blocks_attempt.txt -- so they are gone.)
     unsigned ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = 2; // 2 x 54.5 KB of LDS, 2 x 4 wavefronts of 256 VGPRs
+    // up to 64 queries: the three-independent-wavefronts variant (64 queries per task, 3 busy wavefronts per CU)
+    bool const w3 = nq <= 64u;
+    if (w3) ql_nt = 64u, ql_blocks_per_cu = 3; // counted in wavefront slots
     // kernel choice: the query-lane kernel needs enough queries to fill its lanes
     int kernel = prm->kernel;
     if (kernel == 0)
@@ -802,7 +805,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             unsigned const lmax = len.back();
             double const t_rs = std::max((double)c->sum_core * sum_len / 340e9, lmax * 1.6e-6); // or one pair's row chain
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
-            double const trow = (0.52 + 0.07 * (waves - 1u)) * 1e-6;
+            double const trow = (w3 ? 0.56 : 0.52 + 0.07 * (waves - 1u)) * 1e-6; // w3: + one add per gather
             double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
             double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
                                          (double)c->sum_tiles * sum_block_lmax * trow / resident) +
@@ -823,6 +826,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (two_stage) kernel = 2;
     c->last_kernel = kernel;
     if (two_stage) ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = 1; // 2 x 256 queries' wavefronts, one block per CU
+    bool const use_w3 = w3 && !two_stage;
     if (kernel == 2)
     {
         // queries sorted by length so that the lanes of a block finish together
@@ -940,8 +944,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
         uint64_t fit = per_block ? budget / per_block : 0;
         // one 512-thread block per CU (two-stage) or two 256-thread blocks (single-stage)
-        uint64_t const resident_blocks = (uint64_t)ql_blocks_per_cu * c->num_cus;
-        unsigned const nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, resident_blocks), fit);
+        uint64_t const resident_blocks = (uint64_t)ql_blocks_per_cu * c->num_cus; // w3: wavefront slots, 3 per block
+        unsigned nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, resident_blocks), fit);
+        if (use_w3) nblocks = (nblocks + 2u) / 3u * 3u; // whole 3-slot blocks (scratch is sized for every slot)
         if (nblocks == 0)
             return c->fail(DCP_ENOMEM, "sequence of %u nt is too long for the query-lane kernel: use kernel = 1", qa.lmax);
         size_t const need = (size_t)nblocks * per_block;
@@ -949,7 +954,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.scratch = c->d_scratch.p;
         HIP_TRY(c, hipMemsetAsync(c->d_task_counter.p, 0, sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-        if (two_stage ? dcp_launch_qlane2(&qa, nblocks, c->stream) : dcp_launch_qlane(&qa, nblocks, NT, c->stream))
+        if (two_stage ? dcp_launch_qlane2(&qa, nblocks, c->stream)
+                      : use_w3 ? dcp_launch_qlane_w3(&qa, nblocks / 3u, c->stream)
+                               : dcp_launch_qlane(&qa, nblocks, NT, c->stream))
             return c->fail(DCP_EFAIL, "query-lane launch failed");
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], c->stream));

@@ -165,6 +165,8 @@ int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, voi
 // two-stage variant: 512-thread blocks, one per CU; != 0 if the kernel cannot be configured
 int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream);
 unsigned dcp_qlane2_lds_bytes(void);
+// small batches: three independent 64-query wavefronts per 192-thread block, one block per CU
+int dcp_launch_qlane_w3(dcp_qlane_args const *a, unsigned nblocks, void *stream);
 int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream);
 void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
 unsigned dcp_qlane_block_size(void);

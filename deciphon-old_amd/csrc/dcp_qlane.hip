@@ -986,6 +986,110 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small batches (<= 64 queries): three INDEPENDENT wavefronts per block, each with its own 54.5 KB slice
+// of the CU's LDS (tile image + insert/background table) and its own (profile, 64-query block) task
+// stream.  With so few queries the 256-query kernel has one busy wavefront per block and LDS lets two
+// blocks share a CU: two busy wavefronts per CU.  Three 64-thread blocks do not fit (allocation
+// granularity), ONE 160 KiB block with three slices does: three busy wavefronts per CU.  No barrier is
+// needed anywhere -- a wavefront's LDS operations execute in order and nobody else touches its slice.
+// The slices' bases are not compile-time constants of the row code, so each gather address pays one add
+// (+10 VALU per row, 4 %).  Same rows (ql_row), same results.
+// ---------------------------------------------------------------------------------------------------
+template <int G, int D>
+__global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args a)
+{
+    constexpr int NT = 64;
+    constexpr int KT = 4 * G;
+    constexpr int TAB_FLOATS = G * NC * 4;
+    constexpr int SLICE = TAB_FLOATS + 2 * NC;
+    __shared__ __attribute__((aligned(16))) float lds[3 * SLICE];
+    unsigned const wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned const tid = threadIdx.x & 63u;
+    float *const tabM = lds + wv * SLICE;
+    float2 *const tabIN = reinterpret_cast<float2 *>(tabM + TAB_FLOATS);
+    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
+    float *const sc = a.scratch + ((size_t)blockIdx.x * 3u + wv) * kPlanes * plane;
+
+    for (;;)
+    {
+        unsigned t0 = 0;
+        if (tid == 0) t0 = atomicAdd(a.task_counter, 1u);
+        unsigned const task = __builtin_amdgcn_readfirstlane(t0); // lane 0's value
+        if (task >= a.ntasks) break;
+        unsigned const slot = a.nprof - 1u - task / a.nqblocks; // biggest profiles first
+        unsigned const qb = task % a.nqblocks;
+        dcp_ql_prof const pm = a.profs[slot];
+        unsigned const T = pm.ntiles;
+
+        unsigned const qi = qb * (unsigned)NT + tid;
+        bool const has = qi < a.nseqs;
+        unsigned const q = has ? a.qorder[qi] : 0u;
+        unsigned const L = has ? a.seq_len[q] : 0u;
+        uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
+        LaneXt xt;
+        {
+            float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
+            xt.RR = x[DCP_X_RR], xt.SB = x[DCP_X_SB], xt.SN = x[DCP_X_SN], xt.NN = x[DCP_X_NN];
+            xt.NB = x[DCP_X_NB], xt.ET = x[DCP_X_ET], xt.EC = x[DCP_X_EC], xt.CC = x[DCP_X_CC];
+            xt.CT = x[DCP_X_CT], xt.EB = x[DCP_X_EB], xt.EJ = x[DCP_X_EJ], xt.JJ = x[DCP_X_JJ];
+            xt.JB = x[DCP_X_JB];
+        }
+        {
+            float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
+            float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
+            for (unsigned i = tid; i < (unsigned)NC; i += (unsigned)NT)
+                tabIN[i] = float2{gi[i], gn[i]};
+        }
+        SweepOut o{ninf(), ninf(), ninf()};
+        bool dirty = false;
+        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
+        for (unsigned t = 0; t < T; ++t)
+        {
+            {
+                float4 const *__restrict__ src =
+                    reinterpret_cast<float4 const *>(a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
+                float4 *dst = reinterpret_cast<float4 *>(tabM);
+                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
+                    dst[i] = src[i];
+            }
+            compiler_fence(); // the sweep's gathers stay behind the image's stores (same wavefront: LDS keeps the order)
+            if (Lwave == 0u) continue;
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
+            bool const first = t == 0, last = t + 1 == T;
+#define QLW_SWEEP(F, L_)                                                                                  \
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{})
+            if (first && last) QLW_SWEEP(true, true);
+            else if (first) QLW_SWEEP(true, false);
+            else if (last) QLW_SWEEP(false, true);
+            else QLW_SWEEP(false, false);
+#undef QLW_SWEEP
+            compiler_fence(); // ... and the next image's stores behind this sweep's gathers
+        }
+        if (has && dirty)
+        {
+            unsigned const cls = pm.cls;
+            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
+            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
+            else *a.redo_overflow = 1u;
+        }
+        else if (has)
+        {
+            float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
+            float const nul = o.Rn;
+            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
+            if (a.out_null) a.out_null[oi] = nul;
+            if (a.out_alt) a.out_alt[oi] = alt;
+            float const lrt = -2 * (nul - alt);
+            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+            {
+                unsigned const h = atomicAdd(a.nhits, 1u);
+                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+            }
+        }
+    }
+}
+
 // words_t[wt_off[qb] + w * NT + t] = word w of the query in lane t of block qb (0 past its end)
 template <int NT>
 __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
@@ -1025,13 +1129,21 @@ extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
 
 extern "C" int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream)
 {
-    if (nt == DCP_QLANE_NT)
+    if (nt == 64) hipLaunchKernelGGL((transpose_words_kernel<64>), dim3(a->nqblocks), dim3(64), 0, (hipStream_t)stream, *a);
+    else if (nt == DCP_QLANE_NT)
         hipLaunchKernelGGL((transpose_words_kernel<DCP_QLANE_NT>), dim3(a->nqblocks), dim3(DCP_QLANE_NT), 0, (hipStream_t)stream, *a);
     else return 1;
     return 0;
 }
 
 extern "C" unsigned dcp_qlane2_lds_bytes(void) { return kL2Bytes; }
+
+// three independent 64-query wavefronts per block (small batches): nblocks blocks of 192 threads
+extern "C" int dcp_launch_qlane_w3(dcp_qlane_args const *a, unsigned nblocks, void *stream)
+{
+    hipLaunchKernelGGL((viterbi_qlane_w3_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(192), 0, (hipStream_t)stream, *a);
+    return 0;
+}
 
 extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
