@@ -329,16 +329,26 @@ def main():
     kernel_id = {"auto": dcp.KERNEL_AUTO, "rowsweep": dcp.KERNEL_ROWSWEEP, "qlane": dcp.KERNEL_QLANE,
                  "qlane2": dcp.KERNEL_QLANE2}[args.kernel]
 
+    cdist_state = {"comm": cdist, "kind": gather_kind}
+
     def step(i):
         sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep),
                 kernel=kernel_id)
         sc.sync()
-        if cdist:
-            h, total = cdist.gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
-            if i < args.warmup:  # untimed cross-check of the C gather against a torch collective
-                tot = hit_count.to(torch.int64).clone()
-                dist.all_reduce(tot)
-                assert int(tot.item()) == total == len(h), (int(tot.item()), total, len(h))
+        if cdist_state["comm"]:
+            h, total = cdist_state["comm"].gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
+            if i < args.warmup:
+                # untimed cross-check of the C gather against the torch.distributed transport, record for record;
+                # every rank takes the same decision, and a mismatch demotes the run to the torch transport
+                ref = ddist.gather_hits(hit_words, hit_count, b)
+                same = torch.tensor([1 if (total == len(h) == len(ref) and np.array_equal(h, ref)) else 0],
+                                    dtype=torch.int32, device="cuda")
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                if int(same.item()) != 1:
+                    cdist_state["comm"].close()
+                    cdist_state["comm"] = None
+                    cdist_state["kind"] = "torch.distributed all_gather + dcp_dist_merge_hits (the C RCCL gather DISAGREED in warm-up)"
+                    h = ref
         elif world > 1 or force_dist:
             h = ddist.gather_hits(hit_words, hit_count, b)
         else:
@@ -496,7 +506,7 @@ def main():
                 "kernel": args.kernel,
                 "dense_families": args.dense or None, "dense_queries": (None if not args.dense else
                                                                          "random" if args.dense_random else "consensus"),
-                "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({gather_kind})" if (world > 1 or force_dist) else ""),
+                "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({cdist_state['kind']})" if (world > 1 or force_dist) else ""),
             },
             "roofline": roof,
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
@@ -515,8 +525,8 @@ def main():
                                    "hits_total": len(found)}
         print(json.dumps(out))
     sc.close()
-    if cdist:
-        cdist.close()
+    if cdist_state["comm"]:
+        cdist_state["comm"].close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
