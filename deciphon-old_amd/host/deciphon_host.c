@@ -11,6 +11,7 @@
 #include "deciphon_host.h"
 #include "host_internal.h"
 
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -219,6 +220,10 @@ uint8_t *dcp_host_seq_ids(struct imm_seq const *seq, enum rc *rc)
  * reference's tests do); thread_run owns one context per partition instead */
 static dcp_gpu_ctx *g_ctx;
 static dcp_profile *g_ctx_db;
+/* the reference calls imm_dp_viterbi from every thread of its OpenMP team (scan.c:239-249): the shared
+ * context serialises such callers instead of racing (thread_run has a context per partition and never
+ * comes here) */
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void release_shared_ctx(void)
 {
@@ -239,10 +244,23 @@ static dcp_gpu_ctx *shared_ctx(void)
 
 void dcp_host_forget_profile(dcp_profile *impl)
 {
-    if (impl && g_ctx_db == impl) g_ctx_db = NULL;
+    if (!impl) return;
+    pthread_mutex_lock(&g_ctx_lock);
+    if (g_ctx_db == impl) g_ctx_db = NULL;
+    pthread_mutex_unlock(&g_ctx_lock);
 }
 
+static enum imm_rc viterbi_locked(struct imm_dp const *dp, struct imm_task *task, struct imm_prod *prod);
+
 enum imm_rc imm_dp_viterbi(struct imm_dp const *dp, struct imm_task *task, struct imm_prod *prod)
+{
+    pthread_mutex_lock(&g_ctx_lock);
+    enum imm_rc rc = viterbi_locked(dp, task, prod);
+    pthread_mutex_unlock(&g_ctx_lock);
+    return rc;
+}
+
+static enum imm_rc viterbi_locked(struct imm_dp const *dp, struct imm_task *task, struct imm_prod *prod)
 {
     if (!dp || !task || !prod || !task->seq) return IMM_FAILURE;
     struct protein_profile *prof = dp->owner;

@@ -458,6 +458,43 @@ static void scan_run_batched(void)
     fclose(fp);
 }
 
+/* The reference calls imm_dp_viterbi from every thread of an OpenMP team (scan.c:239-249, through its own
+ * thread_run): callers that share the library's single-pair context must be serialised, not race. */
+static void concurrent_viterbi(void)
+{
+    enum { NT = 8 };
+    struct imm_nuclt_code code;
+    imm_nuclt_code_init(&code, imm_super(&imm_dna_iupac));
+    static struct protein_profile prof[NT];
+    imm_float serial[NT], parallel[NT];
+    for (unsigned t = 0; t < NT; ++t)
+    {
+        protein_profile_init(&prof[t], "p", &imm_amino_iupac, &code, PROTEIN_CFG_DEFAULT);
+        CHECK(protein_profile_sample(&prof[t], 50 + t, 5 + 3 * t) == RC_OK);
+        CHECK(protein_profile_setup(&prof[t], sizeof query - 1, true, false) == RC_OK);
+    }
+    for (int pass = 0; pass < 2; ++pass)
+    {
+#pragma omp parallel for num_threads(NT) schedule(static, 1) if (pass == 1)
+        for (unsigned t = 0; t < NT; ++t)
+        {
+            struct imm_seq seq = imm_seq(IMM_STR(query), prof[t].super.code->abc);
+            struct imm_prod prod = imm_prod();
+            struct imm_task *task = imm_task_new(&prof[t].alt.dp);
+            enum imm_rc rc = imm_task_setup(task, &seq);
+            if (!rc) rc = imm_dp_viterbi(&prof[t].alt.dp, task, &prod);
+            (pass ? parallel : serial)[t] = rc ? NAN : prod.loglik;
+            imm_del(task);
+            imm_del(&prod);
+        }
+    }
+    for (unsigned t = 0; t < NT; ++t)
+    {
+        CHECK(isfinite(serial[t]) && serial[t] == parallel[t]);
+        profile_del(&prof[t].super);
+    }
+}
+
 /* One process per GPU, in C: shard map, communicator through the file rendezvous, scan, RCCL gather.
  * One rank is all a single-GPU box allows (RCCL refuses two ranks on one device); it still runs
  * dlopen(librccl), ncclCommInitRank, the counts all-gather, the local leg of the gather-v and the merge. */
@@ -571,6 +608,7 @@ int main(void)
     scan_run_batched();
     remove(g_db_path);
     one_process_per_gpu();
+    concurrent_viterbi();
     CHECK(xmath_partition_size(20000, 8, 7) == 2500);
     CHECK(fabsf(xmath_lrt(-48.927f, -54.355f) - (-10.856f)) < 1e-3f);
     if (failed) fprintf(stderr, "%d check(s) failed\n", failed);
