@@ -235,6 +235,11 @@ static enum rc thread_prepare(struct scan_thread *t, int tid)
         if (!t->gpu) return fail(RC_EFAIL, "failed to create the device context");
     }
     if (t->db_resident) return RC_OK;
+    /* a previous attempt that failed half way left profiles behind: start over */
+    for (unsigned i = 0; i < t->nimpls; ++i)
+        dcp_profile_del(t->impls[i]);
+    free(t->impls);
+    t->nimpls = 0;
     t->impls = calloc(n ? n : 1, sizeof *t->impls);
     if (!t->impls) return fail(RC_ENOMEM, "alloc");
     enum rc rc = profile_reader_rewind(reader, t->id);
@@ -489,6 +494,7 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
         }
         if (rc || nb == 0) break;
         enum rc shared = RC_OK;
+        if (nparts == 0) continue; /* an empty database: every sequence is consumed, nothing is scored */
 #pragma omp parallel for schedule(static, 1) num_threads(nparts)
         for (unsigned i = 0; i < nparts; ++i)
         {
