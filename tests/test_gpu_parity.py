@@ -456,8 +456,9 @@ def test_random_api_sequences(dcp, scanner):
             hi = int(rng.integers(lo + 1, n + 1))
             q_range = None if rng.random() < 0.4 else (lo, hi)
             multi, h3 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-            first = [dcp.KERNEL_QLANE, dcp.KERNEL_ROWSWEEP, dcp.KERNEL_AUTO][int(rng.integers(0, 3))]
-            other = dcp.KERNEL_ROWSWEEP if first == dcp.KERNEL_QLANE else dcp.KERNEL_QLANE
+            first = [dcp.KERNEL_QLANE, dcp.KERNEL_ROWSWEEP, dcp.KERNEL_AUTO, dcp.KERNEL_QLANE2][int(rng.integers(0, 4))]
+            other = dcp.KERNEL_ROWSWEEP if first in (dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2) else \
+                [dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2][int(rng.integers(0, 2))]
             sl = slice(0, n) if q_range is None else slice(lo, hi)
             res = []
             for k in (first, other):
