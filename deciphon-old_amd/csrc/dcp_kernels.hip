@@ -20,6 +20,14 @@ namespace
 
 __device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
 
+// Read-only inputs at wave-uniform addresses (sequence words, background / insert emissions, the
+// query's special transitions) are read through the constant address space: they become scalar loads
+// into SGPRs -- free operands of the VALU -- instead of 64 lanes loading the same dword.
+typedef float const __attribute__((address_space(4))) cfloat;
+typedef uint32_t const __attribute__((address_space(4))) cu32;
+__device__ __forceinline__ cfloat *as_const(float const *p) { return (cfloat *)(unsigned long long)p; }
+__device__ __forceinline__ cu32 *as_const(uint32_t const *p) { return (cu32 *)(unsigned long long)p; }
+
 // ---- cross-lane helpers (wave64 DPP) ---------------------------------------
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov(float old_value, float v)
@@ -35,6 +43,10 @@ __device__ __forceinline__ float lane_shr1(float v, float first)
 {
     return dpp_mov<0x138 /*wave_shr:1*/, 0xf, 0xf>(first, v);
 }
+
+// lane ^ 1 and lane ^ 2 inside each group of four lanes
+__device__ __forceinline__ float quad_xor1(float v) { return dpp_mov<0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf>(v, v); }
+__device__ __forceinline__ float quad_xor2(float v) { return dpp_mov<0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf>(v, v); }
 
 // max over the 64 lanes, returned wave-uniform
 __device__ __forceinline__ float wave_max(float v)
@@ -97,11 +109,22 @@ __device__ __forceinline__ unsigned code_of(unsigned w, int l)
 }
 
 // ---- per-pair DP state held in registers -----------------------------------
+// The four emitting special states -- N, J, C of the alt model and R of the null model -- share one
+// recursion shape, X(j) = max_l (PX(j-l) + e_bg(x[j-l..j))), PX(j) = max(E(j) + a, X(j) + b).  Lane t
+// runs it for special t & 3 (0 N, 1 J, 2 C, 3 R) with its own a / b in registers, so a row pays for
+// one such recursion instead of four; B(j) is put together inside each group of four lanes.
 template <int R> struct PairState
 {
     float P[5][R]; // P_k(j') = best predecessor of M_k leaving row j', slot j' % 5
     float Q[5][R]; // Q_k(j') = best predecessor of I_k
-    float PN[5], PJ[5], PC[5], PR[5]; // same for N, J, C (alt) and R (null)
+    float PX[5];   // same for this lane's special state
+};
+
+struct LaneSpecial
+{
+    float a; // E -> X:      -inf, EJ, EC, -inf
+    float b; // X -> X:      NN, JJ, CC, RR
+    float c; // X -> B:      NB, JB, -inf, -inf
 };
 
 template <int R> struct Trans
@@ -111,7 +134,8 @@ template <int R> struct Trans
 
 struct RowOut
 {
-    float E, C, Rn;
+    float E; // wave-uniform
+    float X; // this lane's special: N, J, C or R of the row
 };
 
 // Cross-wavefront exchange area of one block (W > 1 only).  Slots are indexed by
@@ -127,15 +151,16 @@ template <int W> struct Exchange
 // One DP row. PH = j % 5 is compile-time so the history ring needs no moves.
 // W == 1: the wavefront owns the whole profile. W > 1: wavefront `wave` owns
 // nodes [wave*64*R, (wave+1)*64*R) and exchanges boundary values through LDS.
-template <int R, int W, int PH>
+// `fetch` loads the NEXT row's emissions into em / eN / eI; it is called as soon as this row
+// has consumed them (one set of registers, no copies), and its loads land during the
+// cross-lane part of the row.
+template <int R, int W, int PH, class Fetch>
 __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
-                                         float const (&em)[5][R],
-                                         float const (&eN)[5],
-                                         float const (&eI)[5],
-                                         float const *__restrict__ xt,
+                                         float (&em)[5][R], float (&eN)[5], float (&eI)[5],
+                                         LaneSpecial const &sp, float const xEB,
                                          Exchange<(W > 1 ? W : 1)> *xc,
                                          unsigned wave, unsigned lane,
-                                         unsigned &gen)
+                                         unsigned &gen, Fetch &&fetch)
 {
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5,
                   s4 = (PH + 1) % 5, s5 = PH;
@@ -152,36 +177,35 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
         ins[r] = max5(s.Q[s1][r] + eI[0], s.Q[s2][r] + eI[1], s.Q[s3][r] + eI[2],
                       s.Q[s4][r] + eI[3], s.Q[s5][r] + eI[4]);
     }
-    float const N = max5(s.PN[s1] + eN[0], s.PN[s2] + eN[1], s.PN[s3] + eN[2],
-                         s.PN[s4] + eN[3], s.PN[s5] + eN[4]);
-    float const J = max5(s.PJ[s1] + eN[0], s.PJ[s2] + eN[1], s.PJ[s3] + eN[2],
-                         s.PJ[s4] + eN[3], s.PJ[s5] + eN[4]);
-    float const C = max5(s.PC[s1] + eN[0], s.PC[s2] + eN[1], s.PC[s3] + eN[2],
-                         s.PC[s4] + eN[3], s.PC[s5] + eN[4]);
-    float const Rn = max5(s.PR[s1] + eN[0], s.PR[s2] + eN[1], s.PR[s3] + eN[2],
-                          s.PR[s4] + eN[3], s.PR[s5] + eN[4]);
+    float const X = max5(s.PX[s1] + eN[0], s.PX[s2] + eN[1], s.PX[s3] + eN[2],
+                         s.PX[s4] + eN[3], s.PX[s5] + eN[4]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch();
+    __builtin_amdgcn_sched_barrier(0);
 
     // Delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
     // a lane; across lanes (and wavefronts) iterate to the fixed point, which
     // is the sequential recurrence's unique solution -- exact, no reassociation.
+    // A pass starts with the first node only: when no lane's D changes there (the usual case
+    // after the first pass), the rest of the lane's chain cannot change either.
     float m_first = ni, i_first = ni, d_first = ni; // node k-1 of lane 0
     float m_left = lane_shr1(m[R - 1], m_first);
     float i_left = lane_shr1(ins[R - 1], i_first);
     float a[R], d[R], d_left;
-    auto chain = [&]() {
-        a[0] = m_left + t.md[0];
 #pragma unroll
-        for (int r = 1; r < R; ++r)
-            a[r] = m[r - 1] + t.md[r];
+    for (int r = 1; r < R; ++r)
+        a[r] = m[r - 1] + t.md[r];
+    auto refine = [&]() {
+        a[0] = m_left + t.md[0];
         for (;;)
         {
             d_left = lane_shr1(d[R - 1], d_first);
-            float const before = d[R - 1];
-            d[0] = fmaxf(a[0], d_left + t.dd[0]);
+            float const d0 = fmaxf(a[0], d_left + t.dd[0]);
+            if (!__any(d0 != d[0])) break;
+            d[0] = d0;
 #pragma unroll
             for (int r = 1; r < R; ++r)
                 d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
-            if (!__any(d[R - 1] != before)) break;
         }
     };
     auto lane_max = [&]() {
@@ -191,10 +215,12 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
             e = fmaxf(e, fmaxf(m[r], d[r]));
         return e;
     };
+    // first pass: every lane's chain from its own M values (left neighbour's D not known yet)
+    d[0] = m_left + t.md[0];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        d[r] = ni;
-    chain();
+    for (int r = 1; r < R; ++r)
+        d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+    refine();
 
     // E = max over nodes of M_k and D_k (exit scores are 0: protein_model.c:441-458)
     float E;
@@ -244,12 +270,14 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                 }
                 d_first = xc->d[buf][wave - 1];
             }
-            chain();
+            refine();
         }
     }
 
-    // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf)
-    float const B = fmaxf(fmaxf(N + xt[DCP_X_NB], E + xt[DCP_X_EB]), J + xt[DCP_X_JB]);
+    // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf): lanes t & 3 = 0, 1 hold N, J
+    float const xb = X + sp.c;
+    float const xb2 = fmaxf(xb, quad_xor1(xb));
+    float const B = fmaxf(fmaxf(xb2, quad_xor2(xb2)), E + xEB);
 
     // predecessors leaving this row (overwrite the slot of row j-5)
     {
@@ -264,15 +292,17 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
             pm = m[r], pi = ins[r], pd = d[r];
         }
     }
-    s.PN[PH] = N + xt[DCP_X_NN];
-    s.PJ[PH] = fmaxf(E + xt[DCP_X_EJ], J + xt[DCP_X_JJ]);
-    s.PC[PH] = fmaxf(E + xt[DCP_X_EC], C + xt[DCP_X_CC]);
-    s.PR[PH] = Rn + xt[DCP_X_RR];
-    return RowOut{E, C, Rn};
+    s.PX[PH] = fmaxf(E + sp.a, X + sp.b);
+    return RowOut{E, X};
 }
 
-__device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words,
-                                            unsigned pos)
+// base `pos` of the sequence (a scalar load: the address is wave-uniform)
+__device__ __forceinline__ unsigned base_at(cu32 *words, unsigned pos)
+{
+    return (words[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
+}
+
+__device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words, unsigned pos)
 {
     return (words[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
 }
@@ -280,8 +310,7 @@ __device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words,
 template <int R>
 __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
                                          unsigned ldk, unsigned lane_off,
-                                         float const *__restrict__ eN_tab,
-                                         float const *__restrict__ eI_tab,
+                                         cfloat *eN_tab, cfloat *eI_tab,
                                          unsigned w, float (&em)[5][R],
                                          float (&eN)[5], float (&eI)[5])
 {
@@ -339,11 +368,16 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
         q0 = (task - s_rel * a.nchunks) * a.qchunk;
         q1 = min(q0 + a.qchunk, a.nseqs);
     }
+    // the task is the same for every lane of the wavefront: say so, and everything derived from
+    // it (table bases, sequence words, window codes) stays in SGPRs
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    q0 = __builtin_amdgcn_readfirstlane(q0);
+    q1 = __builtin_amdgcn_readfirstlane(q1);
 
     dcp_prof_meta const pm = a.profs[slot];
     float const *__restrict__ em_base = a.emis_match + pm.emis_off;
-    float const *__restrict__ eN_tab = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
-    float const *__restrict__ eI_tab = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
+    cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
+    cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
     unsigned const ldk = pm.ldk;
     unsigned const lane_off = ((W == 1 ? 0u : wave * 64u) + lane) * R;
     unsigned gen = 0;
@@ -370,9 +404,15 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
     for (unsigned q = q0; q < q1; ++q)
     {
         unsigned const L = a.seq_len[q];
-        uint32_t const *__restrict__ words = a.seq_words + a.seq_woff[q];
-        float const *__restrict__ xt = a.xtrans + (size_t)q * DCP_XSTRIDE;
+        cu32 *words = as_const(a.seq_words + a.seq_woff[q]);
+        cfloat *xt = as_const(a.xtrans + (size_t)q * DCP_XSTRIDE);
         float const ni = neg_inf();
+        unsigned const x = lane & 3u; // this lane's special state: 0 N, 1 J, 2 C, 3 R
+        LaneSpecial sp;
+        sp.a = x == 1u ? xt[DCP_X_EJ] : x == 2u ? xt[DCP_X_EC] : ni;
+        sp.b = x == 0u ? xt[DCP_X_NN] : x == 1u ? xt[DCP_X_JJ] : x == 2u ? xt[DCP_X_CC] : xt[DCP_X_RR];
+        sp.c = x == 0u ? xt[DCP_X_NB] : x == 1u ? xt[DCP_X_JB] : ni;
+        float const xEB = xt[DCP_X_EB];
 
         // row 0: S = 0, B = S + SB, everything else -inf
         PairState<R> s;
@@ -382,36 +422,31 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 s.P[h][r] = ni, s.Q[h][r] = ni;
-            s.PN[h] = ni, s.PJ[h] = ni, s.PC[h] = ni, s.PR[h] = ni;
+            s.PX[h] = ni;
         }
         {
             float const B0 = 0.0f + xt[DCP_X_SB];
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 s.P[0][r] = B0 + t.ent[r];
-            s.PN[0] = 0.0f + xt[DCP_X_SN];
-            s.PR[0] = 0.0f; // start lprob of R (protein_model.c:224)
+            // PN(0) = S + SN; PR(0) = start lprob of R = 0 (protein_model.c:224)
+            s.PX[0] = x == 0u ? 0.0f + xt[DCP_X_SN] : x == 3u ? 0.0f : ni;
         }
 
         float em[5][R], eN[5], eI[5];
-        float emn[5][R], eNn[5], eIn[5];
         unsigned w = base_at(words, 0);
         load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, em, eN, eI);
-        RowOut o{ni, ni, ni};
+        RowOut o{ni, ni};
         unsigned j = 1;
 
-// compute row j with the tables already in registers while the loads of row
-// j+1 are in flight (the word one past the last base is padding: harmless)
+// compute row j from the tables in registers; once consumed they are refilled for row j+1
+// (the word one past the last base is padding: harmless)
 #define DCP_ROW(PH)                                                            \
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
-        load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, emn, eNn, eIn); \
-        o = dp_row<R, W, PH>(s, t, em, eN, eI, xt, xc, wave, lane, gen);       \
-        _Pragma("unroll") for (int l = 0; l < 5; ++l)                          \
-        {                                                                      \
-            _Pragma("unroll") for (int r = 0; r < R; ++r) em[l][r] = emn[l][r]; \
-            eN[l] = eNn[l], eI[l] = eIn[l];                                    \
-        }                                                                      \
+        o = dp_row<R, W, PH>(s, t, em, eN, eI, sp, xEB, xc, wave, lane, gen, [&]() { \
+            load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, em, eN, eI); \
+        });                                                                    \
         ++j;                                                                   \
     }
         while (j + 4 <= L)
@@ -424,8 +459,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
         if (j <= L) DCP_ROW(4)
 #undef DCP_ROW
 
-        float const alt = fmaxf(o.E + xt[DCP_X_ET], o.C + xt[DCP_X_CT]);
-        float const nul = o.Rn;
+        // C(L) and R(L) sit in lanes 2 and 3
+        float const C = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 2));
+        float const nul = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 3));
+        float const alt = fmaxf(o.E + xt[DCP_X_ET], C + xt[DCP_X_CT]);
         if (threadIdx.x == (W == 1 ? wave * 64u : 0u))
         {
             size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
