@@ -30,9 +30,15 @@ struct SizeClass
     int R, W;
     unsigned cap() const { return 64u * (unsigned)R * (unsigned)W; }
 };
-constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1},  {4, 1},  {3, 2},  {4, 2},
-                                  {3, 4}, {4, 4}, {3, 8},  {4, 8},  {3, 16}, {4, 16}};
+// One wavefront with up to 8 nodes per lane covers core sizes up to 512 (97 % of a Pfam-like DB) without
+// any cross-wavefront exchange; measured on the C3 DB, R = 5..8 in one wavefront take 0.52 / 0.66 of the
+// time of the two-wavefront classes R = 3, 4 they replace, while two wavefronts of 6 or 8 nodes per lane
+// (two per SIMD: too few to hide the block barriers) are slower than four of 3 or 4
+// (profiles/r02/rowsweep_tuning.txt).
+constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1},
+                                  {3, 4}, {4, 4}, {3, 8}, {4, 8}, {3, 16}, {4, 16}};
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
+static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
 
 int class_of(unsigned M)
 {
@@ -326,6 +332,10 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             for (int row = 0; row < 8; ++row)
                 std::memcpy(&t8[m.trans_off + (size_t)row * m.ldk], src + (size_t)row * m.core_size,
                             sizeof(float) * m.core_size);
+            // The first node has no predecessor node: whatever a caller-built profile (dcp_profile_from_parts)
+            // holds there, the edges into it are -inf.  The row sweep relies on it (lane 0 adds them to 0).
+            for (int row : {DCP_T_MM, DCP_T_IM, DCP_T_DM, DCP_T_MD, DCP_T_DD})
+                t8[m.trans_off + (size_t)row * m.ldk] = ninf;
         }
         HIP_TRY(c, hipMemcpyAsync(c->d_trans8.p, t8.data(), t8.size() * sizeof(float),
                                   hipMemcpyHostToDevice, c->stream));
@@ -769,7 +779,12 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     a.nprof_total = c->nprof;
     a.nseqs = nq;
     a.q_base = q_begin;
+    // queries a row-sweep wavefront scores one after the other with the profile's transitions in
+    // registers -- fewer when the DB is small: the grid needs some 16k tasks to fill the chip
+    // (25 profiles x 256 queries: 8.8 ms at 8 per task)
     a.qchunk = nq >= 4096 ? 32u : (nq >= 256 ? 8u : 1u);
+    while (a.qchunk > 1u && (uint64_t)c->nprof * ((nq + a.qchunk - 1u) / a.qchunk) < 16384u)
+        a.qchunk /= 2u;
     a.nchunks = (nq + a.qchunk - 1) / a.qchunk;
     c->last_q0 = q_begin;
     c->last_q1 = q_end;
@@ -779,6 +794,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     // measured rate is that of two -- profiles/r02/latency_probe_narrow_blocks_attempt.txt -- so they are gone.)
     unsigned ql_nt = dcp_qlane_block_size(), ql_blocks_per_cu = 2; // 2 x 54.5 KB of LDS, 2 x 4 wavefronts of 256 VGPRs
     // up to 64 queries: the three-independent-wavefronts variant (64 queries per task, 3 busy wavefronts per CU)
+    // (since the row sweep went from 370 to 850 Gcell/s the automatic choice no longer reaches it:
+    // 64 queries 283 ms there against 330 ms here; it is what kernel = 2 runs for such batches)
     bool const w3 = nq <= 64u;
     if (w3) ql_nt = 64u, ql_blocks_per_cu = 3; // counted in wavefront slots
     // kernel choice: the query-lane kernel needs enough queries to fill its lanes
@@ -786,13 +803,14 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (kernel == 0)
     {
         {
-            // Cost model fitted to profiles/latency_probe.py and profiles/smalldb_probe.py (it picks
-            // the faster kernel in all 26 measured (DB size, batch size) points):
-            //   row sweep    cells / 340 Gcell/s
+            // Cost model fitted to profiles/latency_probe.py and profiles/smalldb_probe.py:
+            //   row sweep    cells / 850 Gcell/s + one pass over the emission tables at 3 TB/s (a small
+            //                batch streams them from HBM: 20k profiles, 16 queries: 103 ms = 67 + 36)
             //   query lane   max(longest task, all tile rows / resident blocks); a tile row of a block
             //                takes 0.52 us with one busy wavefront, 0.73 us with four.
-            // On the 20k-profile DB the switch comes at 45 queries; a DB of a few hundred profiles
-            // stays with the row sweep up to several hundred queries (its tasks cannot fill the grid).
+            // On the 20k-profile DB the switch comes at about 115 queries (96 queries: 427 vs 510 ms,
+            // 128: 561 vs 514 ms); a DB of a few hundred profiles stays with the row sweep up to
+            // several hundred queries (its tasks cannot fill the grid).
             unsigned const NTq = ql_nt;
             std::vector<unsigned> len(c->seq_len.begin() + q_begin, c->seq_len.begin() + q_end);
             std::sort(len.begin(), len.end());
@@ -803,21 +821,25 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             for (unsigned b = 0; b < nqb; ++b)
                 sum_block_lmax += len[std::min(nq, (b + 1u) * NTq) - 1u];
             unsigned const lmax = len.back();
-            double const t_rs = std::max((double)c->sum_core * sum_len / 340e9, lmax * 1.6e-6); // or one pair's row chain
+            double const t_rs = (double)c->sum_core * sum_len / 850e9 + (double)c->sum_core * (DCP_NCODES * 4.0) / 3e12 +
+                                a.qchunk * lmax * 1.2e-6; // the last task's row chain (1.2 us per row)
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
             double const trow = (w3 ? 0.56 : 0.52 + 0.07 * (waves - 1u)) * 1e-6; // w3: + one add per gather
             double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
             double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
                                          (double)c->sum_tiles * sum_block_lmax * trow / resident) +
                                 1e-4; // its redo launches
-            kernel = t_ql < t_rs ? 2 : 1;
-            // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
-            if (lmax > 200000u) kernel = 1;
             // The two-stage variant (512-thread blocks, two tiles of a profile in flight) wins once the
             // query blocks are mostly full -- measured on the C3 DB (profiles/r02/latency_probe.txt):
-            // 256 queries 664 vs 696 ms, 1024 queries 2600 vs 2724 ms; below that its idle wavefronts
-            // still sit through every barrier (128 queries 586 vs 517 ms).
-            if (kernel == 2 && nq >= 192u) kernel = 3;
+            // 256 queries 641 vs 678 ms, 1024 queries 2508 vs 2657 ms (0.94); below that its idle
+            // wavefronts still sit through every barrier (128 queries 583 vs 514 ms).  With fewer tasks
+            // than blocks fit on the chip it takes 0.66 of the single-stage time (profiles/smalldb_probe.py).
+            bool const stage2 = nq >= 192u;
+            double const fill = std::min(1.0, (double)c->nprof * nqb / (4.0 * c->num_cus));
+            double const t_q = stage2 ? t_ql * (0.66 + 0.28 * fill) : t_ql;
+            kernel = t_q < t_rs ? (stage2 ? 3 : 2) : 1;
+            // a batch with very long sequences cannot keep enough blocks resident: row sweep instead
+            if (lmax > 200000u) kernel = 1;
         }
     }
     if (kernel < 1 || kernel > 3) return c->fail(DCP_EINVAL, "unknown kernel %d", kernel);

@@ -44,21 +44,67 @@ __device__ __forceinline__ float lane_shr1(float v, float first)
     return dpp_mov<0x138 /*wave_shr:1*/, 0xf, 0xf>(first, v);
 }
 
-// lane ^ 1 and lane ^ 2 inside each group of four lanes
-__device__ __forceinline__ float quad_xor1(float v) { return dpp_mov<0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf>(v, v); }
-__device__ __forceinline__ float quad_xor2(float v) { return dpp_mov<0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf>(v, v); }
+// Cross-lane maxima and shifted adds are written as ONE VALU instruction with a DPP operand
+// (v_max_f32_dpp / v_add_f32_dpp) where the compiler would emit three (constant for the lanes
+// without a source, v_mov_b32_dpp, the operation).  A lane without a source keeps the destination's
+// old value; `s_nop 1` covers the two wait states a DPP read of a just-written VGPR needs (the
+// compiler's hazard recogniser does not look inside asm statements).
+
+// max over each group of four lanes, returned in all four
+__device__ __forceinline__ float quad_max(float v)
+{
+    float r;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(v));
+    return r;
+}
+
+// (x of lane - 1) + tr; lane 0 of the wavefront: `first` + tr when HAS_FIRST, else 0 + tr -- used where
+// lane 0 is the profile's first node, whose incoming transitions are -inf (dcp_gpu_db_upload).
+template <bool HAS_FIRST> __device__ __forceinline__ float shr1_add(float x, float first, float tr)
+{
+    float r;
+    if constexpr (HAS_FIRST)
+    {
+        r = first + tr;
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
+            : "+v"(r)
+            : "v"(x), "v"(tr));
+    }
+    else
+    {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+            : "=v"(r)
+            : "v"(x), "v"(tr));
+    }
+    return r;
+}
 
 // max over the 64 lanes, returned wave-uniform
 __device__ __forceinline__ float wave_max(float v)
 {
-    float const ni = neg_inf();
-    float r = fmaxf(v, dpp_mov<0x111, 0xf, 0xf>(ni, v)); // row_shr:1
-    r = fmaxf(r, dpp_mov<0x112, 0xf, 0xf>(ni, v));       // row_shr:2
-    r = fmaxf(r, dpp_mov<0x113, 0xf, 0xf>(ni, v));       // row_shr:3
-    r = fmaxf(r, dpp_mov<0x114, 0xf, 0xe>(ni, r));       // row_shr:4
-    r = fmaxf(r, dpp_mov<0x118, 0xf, 0xc>(ni, r));       // row_shr:8
-    r = fmaxf(r, dpp_mov<0x142, 0xa, 0xf>(ni, r));       // row_bcast:15
-    r = fmaxf(r, dpp_mov<0x143, 0xc, 0xf>(ni, r));       // row_bcast:31
+    float r;
+    asm("v_mov_b32 %0, %1\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(v));
     return __builtin_bit_cast(
         float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
 }
@@ -98,6 +144,49 @@ template <> struct VecLoad<4>
     {
         float4 v = *reinterpret_cast<float4 const *>(p);
         o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    }
+};
+
+template <> struct VecLoad<5>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[5])
+    {
+        float t[3], u[2];
+        VecLoad<3>::ld(p, t);
+        struct __attribute__((packed, aligned(4))) f2 { float x, y; };
+        f2 v = *reinterpret_cast<f2 const *>(p + 3);
+        u[0] = v.x, u[1] = v.y;
+        o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = u[0], o[4] = u[1];
+    }
+};
+template <> struct VecLoad<6>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[6])
+    {
+        float t[3], u[3];
+        VecLoad<3>::ld(p, t);
+        VecLoad<3>::ld(p + 3, u);
+        o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = u[0], o[4] = u[1], o[5] = u[2];
+    }
+};
+template <> struct VecLoad<7>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[7])
+    {
+        struct __attribute__((packed, aligned(4))) f4 { float x, y, z, w; };
+        f4 v = *reinterpret_cast<f4 const *>(p);
+        float u[3];
+        VecLoad<3>::ld(p + 4, u);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w, o[4] = u[0], o[5] = u[1], o[6] = u[2];
+    }
+};
+template <> struct VecLoad<8>
+{
+    static __device__ __forceinline__ void ld(float const *p, float (&o)[8])
+    {
+        float4 v = *reinterpret_cast<float4 const *>(p);
+        float4 w = *reinterpret_cast<float4 const *>(p + 4);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w, o[4] = w.x, o[5] = w.y, o[6] = w.z, o[7] = w.w;
     }
 };
 
@@ -188,19 +277,18 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     // is the sequential recurrence's unique solution -- exact, no reassociation.
     // A pass starts with the first node only: when no lane's D changes there (the usual case
     // after the first pass), the rest of the lane's chain cannot change either.
-    float m_first = ni, i_first = ni, d_first = ni; // node k-1 of lane 0
-    float m_left = lane_shr1(m[R - 1], m_first);
-    float i_left = lane_shr1(ins[R - 1], i_first);
-    float a[R], d[R], d_left;
+    // Node k-1 of a lane's first node sits in lane - 1 (W > 1: of lane 0, in the previous wavefront: *_first).
+    float m_first = ni, i_first = ni, d_first = ni;
+    constexpr bool XW = W > 1; // lane 0 may have a predecessor
+    float a[R], d[R];
 #pragma unroll
     for (int r = 1; r < R; ++r)
         a[r] = m[r - 1] + t.md[r];
     auto refine = [&]() {
-        a[0] = m_left + t.md[0];
+        a[0] = shr1_add<XW>(m[R - 1], m_first, t.md[0]);
         for (;;)
         {
-            d_left = lane_shr1(d[R - 1], d_first);
-            float const d0 = fmaxf(a[0], d_left + t.dd[0]);
+            float const d0 = fmaxf(a[0], shr1_add<XW>(d[R - 1], d_first, t.dd[0]));
             if (!__any(d0 != d[0])) break;
             d[0] = d0;
 #pragma unroll
@@ -216,7 +304,7 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
         return e;
     };
     // first pass: every lane's chain from its own M values (left neighbour's D not known yet)
-    d[0] = m_left + t.md[0];
+    d[0] = shr1_add<XW>(m[R - 1], m_first, t.md[0]);
 #pragma unroll
     for (int r = 1; r < R; ++r)
         d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
@@ -265,8 +353,6 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                 {
                     m_first = xc->m[buf][wave - 1];
                     i_first = xc->i[buf][wave - 1];
-                    m_left = lane_shr1(m[R - 1], m_first);
-                    i_left = lane_shr1(ins[R - 1], i_first);
                 }
                 d_first = xc->d[buf][wave - 1];
             }
@@ -275,22 +361,18 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     }
 
     // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf): lanes t & 3 = 0, 1 hold N, J
-    float const xb = X + sp.c;
-    float const xb2 = fmaxf(xb, quad_xor1(xb));
-    float const B = fmaxf(fmaxf(xb2, quad_xor2(xb2)), E + xEB);
+    float const B = fmaxf(quad_max(X + sp.c), E + xEB);
 
     // predecessors leaving this row (overwrite the slot of row j-5)
-    {
-        float pm = m_left, pi = i_left, pd = d_left;
+    s.P[PH][0] = fmaxf(fmaxf(B + t.ent[0], shr1_add<XW>(m[R - 1], m_first, t.mm[0])),
+                       fmaxf(shr1_add<XW>(ins[R - 1], i_first, t.im[0]), shr1_add<XW>(d[R - 1], d_first, t.dm[0])));
+    s.Q[PH][0] = fmaxf(m[0] + t.mi[0], ins[0] + t.ii[0]);
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-        {
-            float v = fmaxf(fmaxf(B + t.ent[r], pm + t.mm[r]),
-                            fmaxf(pi + t.im[r], pd + t.dm[r]));
-            s.P[PH][r] = v;
-            s.Q[PH][r] = fmaxf(m[r] + t.mi[r], ins[r] + t.ii[r]);
-            pm = m[r], pi = ins[r], pd = d[r];
-        }
+    for (int r = 1; r < R; ++r)
+    {
+        s.P[PH][r] = fmaxf(fmaxf(B + t.ent[r], m[r - 1] + t.mm[r]),
+                           fmaxf(ins[r - 1] + t.im[r], d[r - 1] + t.dm[r]));
+        s.Q[PH][r] = fmaxf(m[r] + t.mi[r], ins[r] + t.ii[r]);
     }
     s.PX[PH] = fmaxf(E + sp.a, X + sp.b);
     return RowOut{E, X};
@@ -307,18 +389,27 @@ __device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words, 
     return (words[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
 }
 
+// The emission rows of one DP row: row `c` of the profile's table starts at a wave-uniform address
+// (SGPR pair, pinned there by the empty asm) and every lane adds its own 32-bit byte offset -- the
+// global_load form with an SGPR base, no per-lane 64-bit address arithmetic.  (`lane_boff` passes
+// through an empty asm so that its zero-extension stays next to the load: hoisted out of the row
+// loop as a 64-bit value it no longer matches that addressing mode.)
+typedef char const __attribute__((address_space(1))) *gchar_ptr;
 template <int R>
 __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
-                                         unsigned ldk, unsigned lane_off,
+                                         unsigned ldk, unsigned lane_boff,
                                          cfloat *eN_tab, cfloat *eI_tab,
                                          unsigned w, float (&em)[5][R],
                                          float (&eN)[5], float (&eI)[5])
 {
+    asm volatile("" : "+v"(lane_boff));
 #pragma unroll
     for (int l = 1; l <= 5; ++l)
     {
         unsigned const c = code_of(w, l);
-        VecLoad<R>::ld(em_base + (size_t)c * ldk + lane_off, em[l - 1]);
+        gchar_ptr row = (gchar_ptr)em_base + c * ldk * 4u; // < 2^32: 1364 codes x 4096 nodes x 4 B
+        asm volatile("" : "+s"(row));
+        VecLoad<R>::ld((float const *)(row + lane_boff), em[l - 1]);
         eN[l - 1] = eN_tab[c];
         eI[l - 1] = eI_tab[c];
     }
@@ -334,8 +425,10 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 //           emission-table reads share one XCD's L2;
 //   W  > 1: block = W cooperating wavefronts on one task.
 // ============================================================================
+// wavefronts per SIMD the register allocation must leave room for (512 VGPRs per SIMD lane)
+constexpr int rs_min_waves(int R) { return R <= 4 ? 4 : 2; }
 template <int R, int W>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
     constexpr unsigned TASKS_PER_BLOCK = W == 1 ? 4u : 1u;
     __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
@@ -435,7 +528,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
 
         float em[5][R], eN[5], eI[5];
         unsigned w = base_at(words, 0);
-        load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, em, eN, eI);
+        load_row<R>(em_base, ldk, lane_off * 4u, eN_tab, eI_tab, w, em, eN, eI);
         RowOut o{ni, ni};
         unsigned j = 1;
 
@@ -445,7 +538,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void viterbi_rowsweep_kernel
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
         o = dp_row<R, W, PH>(s, t, em, eN, eI, sp, xEB, xc, wave, lane, gen, [&]() { \
-            load_row<R>(em_base, ldk, lane_off, eN_tab, eI_tab, w, em, eN, eI); \
+            load_row<R>(em_base, ldk, lane_off * 4u, eN_tab, eI_tab, w, em, eN, eI); \
         });                                                                    \
         ++j;                                                                   \
     }
@@ -1029,9 +1122,8 @@ extern "C" int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a,
         launch_rs<r, w>(a, nblocks, s);                                        \
         return 0;                                                              \
     }
-    DCP_CASE(1, 1) DCP_CASE(2, 1) DCP_CASE(3, 1) DCP_CASE(4, 1)
-    DCP_CASE(3, 2) DCP_CASE(4, 2) DCP_CASE(3, 4) DCP_CASE(4, 4)
-    DCP_CASE(3, 8) DCP_CASE(4, 8) DCP_CASE(3, 16) DCP_CASE(4, 16)
+    DCP_CASE(1, 1) DCP_CASE(2, 1) DCP_CASE(3, 1) DCP_CASE(4, 1) DCP_CASE(5, 1) DCP_CASE(6, 1) DCP_CASE(7, 1)
+    DCP_CASE(8, 1) DCP_CASE(3, 4) DCP_CASE(4, 4) DCP_CASE(3, 8) DCP_CASE(4, 8) DCP_CASE(3, 16) DCP_CASE(4, 16)
 #undef DCP_CASE
     return -1;
 }

@@ -643,11 +643,13 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
             if name == "qlane":
                 redo = sc.last_scan_redo_pairs
         assert 0 < redo < 0.05 * 2e7
-        # kernel = 0 on this DB: the row sweep for a handful of queries, the three-wavefront query-lane variant
-        # from ~31 queries (measured equal at 32: 332 vs 338 ms), the two-stage kernel for full blocks
+        # kernel = 0 on this DB: the row sweep up to about 115 queries (64 queries: 283 ms against 330 ms),
+        # the single-stage query-lane kernel from there, the two-stage one once the blocks are mostly full
         sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 16))
         assert sc.launch_infos()[0]["W"] >= 1 and sc.last_scan_kernel == dcp.KERNEL_ROWSWEEP
         sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 64))
+        assert sc.launch_infos()[0]["W"] >= 1 and sc.last_scan_kernel == dcp.KERNEL_ROWSWEEP
+        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 160))
         assert sc.launch_infos()[0]["W"] == 0 and sc.last_scan_kernel == dcp.KERNEL_QLANE
         sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 1000))
         assert sc.last_scan_kernel == dcp.KERNEL_QLANE2
