@@ -447,7 +447,8 @@ def main():
             "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK / 1e12, 1), "unit": "Tlane-op/s",
             "frac": round(lane_ops / VALU_PEAK, 4),
             "ops_per_cell": OPS_PER_CELL,
-            "peak_note": "256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (spec clock); the kernel sustains ~1.8 GHz under load",
+            "peak_note": ("256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (spec clock); measured clock under this load: two-stage "
+                          "query-lane kernel 2.23 GHz, single-stage 1.81 GHz, row sweep 2.3-2.4 GHz (profiles/r02/*pmc*)"),
             "avg_launch_ms": round(dom_ms, 3),
             "cells_per_launch": int(dom_cells),
             "gcells_per_s": round(dom_cells / (dom_ms * 1e-3) / 1e9, 1),
@@ -461,6 +462,15 @@ def main():
                 "analytic_tile_image_bytes_per_launch": tile_bytes,
                 "compulsory_bytes_per_launch": compulsory,
             },
+            # the row sweep reads SURVEY 8d's 20 B/cell of match emissions from the XCD's L2 (the profile's table is
+            # L2-resident while its queries run): against the chip's measured L2-resident row-gather rate
+            # (MI355X_MICROARCH.md, 'Indexed rows': 16.8-18.8 TB/s) that, not HBM or the VALU, is its bound
+            "l2_gather": (None if is_qlane else {
+                "bytes_per_launch": int(dom_algo_bytes),
+                "gbs": round(dom_algo_bytes / (dom_ms * 1e-3) / 1e9, 1),
+                "peak_gbs": 17800.0,
+                "frac": round(dom_algo_bytes / (dom_ms * 1e-3) / 17.8e12, 3),
+            }),
             # SURVEY.md 8d's per-pair byte model 20*M*L + 32*(M+1) + L + 8: NOT a bound for this design
             "algorithmic_hbm": {
                 "bytes_per_launch": int(dom_algo_bytes),

@@ -325,11 +325,11 @@ def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner):
         scanner.test_set_redo_cap(0)
 
 
-@pytest.mark.parametrize("M", [300, 600, 1300, 2600])
+@pytest.mark.parametrize("M", [300, 400, 450, 600, 1300, 2600])
 def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
-    """A real hit against a big profile leaves the query-lane kernel through the redo list of a
-    multi-wavefront size class (W = 2, 4, 8, 16): the row sweep's pair mode must score it, and every
-    other pair of the scan, bit-exactly."""
+    """A real hit against a big profile leaves the query-lane kernel through the redo list of a many-nodes-
+    per-lane (R = 5, 7, 8) or multi-wavefront (W = 4, 8, 16) size class: the row sweep's pair mode must
+    score it, and every other pair of the scan, bit-exactly."""
     rng = np.random.default_rng(M + 1)
     prm = pfam_like_params(rng, M)
     cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
@@ -506,10 +506,11 @@ def delete_heavy_params(rng, M):
     return null, match, t.astype(np.float32)
 
 
-@pytest.mark.parametrize("sizes", [(257, 300, 384), (385, 512, 513), (700, 768, 1024),
+@pytest.mark.parametrize("sizes", [(257, 300, 384), (320, 321, 448, 449), (385, 512, 513), (700, 768, 1024),
                                    (1025, 1536, 2048), (2049, 3072, 4096)])
 def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes, kern):
-    """Multi-wavefront kernels (core_size > 256), incl. the maximum core size 4096
+    """core_size > 256: the single-wavefront classes with 5..8 nodes per lane (up to 512, both sides of every
+    class boundary) and the multi-wavefront ones, incl. the maximum core size 4096
     (PROTEIN_MODEL_CORE_SIZE_MAX, limits.h:11)."""
     rng = np.random.default_rng(sum(sizes))
     profiles = make_profiles(dcp, [(100 + i, M, ENTRY_DIST_OCCUPANCY, 0.01) for i, M in enumerate(sizes)])
@@ -523,7 +524,7 @@ def test_dp_bit_exact_large_profiles(dcp, oracle32, scanner, sizes, kern):
     assert same_bits(ga, oa)
 
 
-@pytest.mark.parametrize("M", [40, 200, 256, 500, 1000, 2500])
+@pytest.mark.parametrize("M", [40, 200, 256, 300, 420, 500, 1000, 2500])
 def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M, kern):
     rng = np.random.default_rng(M)
     cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
