@@ -463,13 +463,14 @@ def main():
                 "compulsory_bytes_per_launch": compulsory,
             },
             # the row sweep reads SURVEY 8d's 20 B/cell of match emissions from the XCD's L2 (the profile's table is
-            # L2-resident while its queries run): against the chip's measured L2-resident row-gather rate
-            # (MI355X_MICROARCH.md, 'Indexed rows': 16.8-18.8 TB/s) that, not HBM or the VALU, is its bound
+            # L2-resident while its queries run; the rows of the 1- and 2-base words mostly hit the CU's L1):
+            # against the L2 peak (MI355X_MICROARCH.md: 34.5 TB/s; its measured rate for gathering L2-resident
+            # rows into LDS is 16.8-18.8 TB/s) -- that path, not HBM or the VALU, is this kernel's nearest bound
             "l2_gather": (None if is_qlane else {
                 "bytes_per_launch": int(dom_algo_bytes),
                 "gbs": round(dom_algo_bytes / (dom_ms * 1e-3) / 1e9, 1),
-                "peak_gbs": 17800.0,
-                "frac": round(dom_algo_bytes / (dom_ms * 1e-3) / 17.8e12, 3),
+                "peak_gbs": 34500.0,
+                "frac": round(dom_algo_bytes / (dom_ms * 1e-3) / 34.5e12, 3),
             }),
             # SURVEY.md 8d's per-pair byte model 20*M*L + 32*(M+1) + L + 8: NOT a bound for this design
             "algorithmic_hbm": {

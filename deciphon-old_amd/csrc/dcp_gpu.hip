@@ -37,7 +37,12 @@ struct SizeClass
 // (profiles/r02/rowsweep_tuning.txt).
 constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1},
                                   {3, 4}, {4, 4}, {3, 8}, {4, 8}, {3, 16}, {4, 16}};
+// cells/s of each class on a full grid, measured on the C3 and C5 DBs (profiles/r02/rowsweep_tuning.txt): the
+// kernel choice prices a row-sweep scan with them
+constexpr double kClassRate[] = {530e9, 720e9, 930e9, 1030e9, 940e9, 980e9, 1000e9, 1000e9,
+                                 490e9, 600e9, 440e9, 570e9, 400e9, 400e9};
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
+static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
 static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
 
 int class_of(unsigned M)
@@ -97,6 +102,7 @@ struct dcp_gpu_ctx
     int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
     std::vector<dcp_ql_prof> ql_metas; // same order as metas
     uint64_t sum_core = 0, sum_tiles = 0; // over the resident DB (kernel choice)
+    uint64_t class_core[DCP_MAX_CLASSES] = {0}; // sum of core sizes per row-sweep size class
     unsigned max_tiles = 0;
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
@@ -348,6 +354,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     c->ql_metas.assign(nprofiles, dcp_ql_prof{});
     c->sum_core = c->sum_tiles = 0;
     c->max_tiles = 0;
+    for (uint64_t &v : c->class_core)
+        v = 0;
     for (unsigned i = 0; i < nprofiles; ++i)
     {
         dcp_prof_meta const &m = c->metas[i];
@@ -358,6 +366,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         qm.cls = (uint32_t)class_of(m.core_size);
         qm.ntiles = (m.core_size + KT - 1) / KT;
         c->sum_core += m.core_size;
+        c->class_core[qm.cls] += m.core_size;
         c->sum_tiles += qm.ntiles;
         c->max_tiles = std::max(c->max_tiles, qm.ntiles);
         qm.tile_off = tile_floats;
@@ -804,8 +813,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     {
         {
             // Cost model fitted to profiles/latency_probe.py and profiles/smalldb_probe.py:
-            //   row sweep    cells / 850 Gcell/s + one pass over the emission tables at 3 TB/s (a small
-            //                batch streams them from HBM: 20k profiles, 16 queries: 103 ms = 67 + 36)
+            //   row sweep    cells of each size class / that class's rate (kClassRate: 0.5-1.05 Tcell/s with one
+            //                wavefront per pair, 0.4-0.6 with 4-16) + one pass over the emission tables at
+            //                3 TB/s (a small batch streams them from HBM: 20k profiles, 16 queries: 103 ms =
+            //                67 + 36) + the last task's row chain
             //   query lane   max(longest task, all tile rows / resident blocks); a tile row of a block
             //                takes 0.52 us with one busy wavefront, 0.73 us with four.
             // On the 20k-profile DB the switch comes at about 115 queries (96 queries: 427 vs 510 ms,
@@ -821,8 +832,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             for (unsigned b = 0; b < nqb; ++b)
                 sum_block_lmax += len[std::min(nq, (b + 1u) * NTq) - 1u];
             unsigned const lmax = len.back();
-            double const t_rs = (double)c->sum_core * sum_len / 850e9 + (double)c->sum_core * (DCP_NCODES * 4.0) / 3e12 +
-                                a.qchunk * lmax * 1.2e-6; // the last task's row chain (1.2 us per row)
+            double t_rs = (double)c->sum_core * (DCP_NCODES * 4.0) / 3e12 + a.qchunk * lmax * 1.2e-6; // 1.2 us per row
+            for (int k = 0; k < kNumClasses; ++k)
+                t_rs += (double)c->class_core[k] * sum_len / kClassRate[k];
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
             double const trow = (w3 ? 0.56 : 0.52 + 0.07 * (waves - 1u)) * 1e-6; // w3: + one add per gather
             double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
