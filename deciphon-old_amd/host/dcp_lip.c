@@ -128,15 +128,41 @@ bool lip_write_1darray_size_type(struct lip_file *f, unsigned size, uint8_t type
 
 bool lip_write_1darray_u32_item(struct lip_file *f, uint32_t item) { return put_be(f, item, 4); }
 
-bool lip_write_1darray_f32_data(struct lip_file *f, unsigned size, float const *data)
+/* element data of the arrays is big-endian on file; moved in blocks (one stdio call per KiB, not per element:
+ * a 20k-profile database holds half a billion floats) */
+static bool put_be32_block(struct lip_file *f, unsigned size, void const *data)
 {
-    for (unsigned i = 0; i < size; ++i)
+    uint32_t chunk[256];
+    unsigned char const *src = data;
+    while (size)
     {
-        uint32_t bits;
-        memcpy(&bits, data + i, 4);
-        if (!put_be(f, bits, 4)) return false;
+        unsigned const n = size < 256u ? size : 256u;
+        memcpy(chunk, src, (size_t)n * 4);
+        for (unsigned i = 0; i < n; ++i)
+            chunk[i] = __builtin_bswap32(chunk[i]);
+        if (!put(f, chunk, (size_t)n * 4)) return false;
+        src += (size_t)n * 4, size -= n;
     }
     return true;
+}
+
+static bool get_be32_block(struct lip_file *f, unsigned size, void *data)
+{
+    if (!get(f, data, (size_t)size * 4)) return false;
+    unsigned char *p = data;
+    for (unsigned i = 0; i < size; ++i, p += 4)
+    {
+        uint32_t v;
+        memcpy(&v, p, 4);
+        v = __builtin_bswap32(v);
+        memcpy(p, &v, 4);
+    }
+    return true;
+}
+
+bool lip_write_1darray_f32_data(struct lip_file *f, unsigned size, float const *data)
+{
+    return put_be32_block(f, size, data);
 }
 
 bool lip_write_1darray_u8_data(struct lip_file *f, unsigned size, uint8_t const *data) { return put(f, data, size); }
@@ -284,25 +310,12 @@ bool lip_read_1darray_size_type(struct lip_file *f, unsigned *size, enum lip_1da
 
 bool lip_read_1darray_u32_data(struct lip_file *f, unsigned size, uint32_t *data)
 {
-    for (unsigned i = 0; i < size; ++i)
-    {
-        uint64_t v;
-        if (!get_be(f, &v, 4)) return false;
-        data[i] = (uint32_t)v;
-    }
-    return true;
+    return get_be32_block(f, size, data);
 }
 
 bool lip_read_1darray_f32_data(struct lip_file *f, unsigned size, float *data)
 {
-    for (unsigned i = 0; i < size; ++i)
-    {
-        uint64_t v;
-        if (!get_be(f, &v, 4)) return false;
-        uint32_t bits = (uint32_t)v;
-        memcpy(data + i, &bits, 4);
-    }
-    return true;
+    return get_be32_block(f, size, data);
 }
 
 bool lip_read_1darray_u8_data(struct lip_file *f, unsigned size, uint8_t *data) { return get(f, data, size); }
