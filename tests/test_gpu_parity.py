@@ -356,7 +356,7 @@ def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
 def test_kernel_choice_by_batch_size(dcp, scanner):
     """kernel = 0 picks by a cost model: a DB of a few profiles cannot fill the query-lane kernel's
     persistent grid, so it stays with the row sweep at any batch size (the 20k-profile DB switches to the
-    query-lane kernel at 45 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
+    query-lane kernel at about 115 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
     gives the same bits; launch infos tell the two apart."""
     rng = np.random.default_rng(48)
     profiles = make_profiles(dcp, [(900 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((3, 70, 130, 300))])
