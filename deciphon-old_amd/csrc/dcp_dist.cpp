@@ -282,7 +282,10 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
     // 1. {count, profile_offset} of every rank: one all-gather of 2 words
     uint32_t mine[2] = {0, profile_offset};
     DIST_HIP(d, hipMemcpy(&mine[0], nhits_dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (mine[0] > cap) return d->fail(DCP_ENOMEM, "hit buffer overflow", "more hits than the device buffer holds");
+    // A rank whose buffer overflowed still takes part in both exchanges (leaving here would hang its
+    // peers inside the collective): it contributes the records it holds and reports the overflow at the end.
+    bool const overflow = mine[0] > cap;
+    if (overflow) mine[0] = cap;
     DIST_HIP(d, hipMemcpyAsync(d->d_meta_mine, mine, sizeof mine, hipMemcpyHostToDevice, d->stream));
     DIST_NCCL(d, rccl().AllGather(d->d_meta_mine, d->d_meta_all, 2, ncclUint32, d->comm, d->stream));
     std::vector<uint32_t> meta((size_t)2 * R);
@@ -334,7 +337,7 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
     if (!receiver)
     {
         DIST_HIP(d, hipStreamSynchronize(d->stream));
-        return DCP_OK;
+        return overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", "more hits than the device buffer holds") : DCP_OK;
     }
     // 3. to the host; global indices; (seq, profile) order
     std::vector<dcp_hit> raw((size_t)total);
@@ -349,7 +352,7 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
         return d->fail(DCP_EFAIL, "merge", "inconsistent counts");
     }
     *out = res;
-    return DCP_OK;
+    return overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", "more hits than the device buffer holds") : DCP_OK;
 }
 
 void dcp_dist_free_hits(struct dcp_hit *hits) { std::free(hits); }

@@ -101,6 +101,8 @@ class CDist:
         rc = lib.dcp_dist_gather_hits(self._h, hits_dev_ptr, count_dev_ptr, cap, profile_offset, root, scan_stream,
                                       C.byref(out), C.byref(n))
         if rc:
+            if out.value:  # an overflow is reported after the exchange, with the (truncated) list allocated
+                lib.dcp_dist_free_hits(out)
             raise DcpError(rc, lib.dcp_dist_last_error(self._h).decode())
         if not out.value:
             return None, n.value

@@ -414,7 +414,9 @@ void dcp_dist_shard(unsigned const *core_sizes, unsigned nprofiles, int nranks, 
  * Counts + offsets travel in one 2-word all-gather, the records in one grouped ncclSend/ncclRecv
  * (gather-v).  root >= 0: only that rank receives; root < 0: every rank does.  On a receiving rank
  * *out is a malloc'ed array (dcp_dist_free_hits) of *nout records with GLOBAL profile indices,
- * ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total. */
+ * ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total.
+ * A rank whose scan found more than `cap` hits still completes both exchanges with the records it holds
+ * (its peers are not left waiting) and then returns DCP_ENOMEM -- on a receiving rank with *out set. */
 int dcp_dist_gather_hits(dcp_dist *, void const *hits_dev, void const *nhits_dev, unsigned cap,
                          unsigned profile_offset, int root, void *scan_stream, struct dcp_hit **out,
                          unsigned *nout);
