@@ -237,6 +237,17 @@ template <int W> struct Exchange
     int flag[3];
 };
 
+// D of a lane's nodes 1..R-1 from its node 0 (the sequential part of the delete chain)
+template <int R, int r = 1>
+__device__ __forceinline__ void chain_rest(float const (&a)[R], float (&d)[R], float const (&dd)[R])
+{
+    if constexpr (r < R)
+    {
+        d[r] = fmaxf(a[r], d[r - 1] + dd[r]);
+        chain_rest<R, r + 1>(a, d, dd);
+    }
+}
+
 // One DP row. PH = j % 5 is compile-time so the history ring needs no moves.
 // W == 1: the wavefront owns the whole profile. W > 1: wavefront `wave` owns
 // nodes [wave*64*R, (wave+1)*64*R) and exchanges boundary values through LDS.
@@ -291,9 +302,7 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
             float const d0 = fmaxf(a[0], shr1_add<XW>(d[R - 1], d_first, t.dd[0]));
             if (!__any(d0 != d[0])) break;
             d[0] = d0;
-#pragma unroll
-            for (int r = 1; r < R; ++r)
-                d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+            chain_rest<R>(a, d, t.dd);
         }
     };
     auto lane_max = [&]() {
@@ -305,9 +314,7 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     };
     // first pass: every lane's chain from its own M values (left neighbour's D not known yet)
     d[0] = shr1_add<XW>(m[R - 1], m_first, t.md[0]);
-#pragma unroll
-    for (int r = 1; r < R; ++r)
-        d[r] = fmaxf(a[r], d[r - 1] + t.dd[r]);
+    chain_rest<R>(a, d, t.dd);
     refine();
 
     // E = max over nodes of M_k and D_k (exit scores are 0: protein_model.c:441-458)
