@@ -30,11 +30,12 @@ for p in $PASSES; do
     write) run pmc_write --pmc WRITE_SIZE ;;
     sq)    run pmc_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE ;;
     lds)   run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM ;;
+    l2)    run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum ;;   # not in the default set: PASSES="... l2"
   esac
 done
 cd "$ROOT"
 DIRS=""
-for d in pmc_fetch pmc_write pmc_sq pmc_lds; do [ -d "$OUT/$d" ] && DIRS="$DIRS $OUT/$d"; done
+for d in pmc_fetch pmc_write pmc_sq pmc_lds pmc_l2; do [ -d "$OUT/$d" ] && DIRS="$DIRS $OUT/$d"; done
 [ -n "$DIRS" ] && python3 profiles/pmc_summary.py "$OUT/pmc.json" $DIRS > "$OUT/pmc_derived.txt" && cat "$OUT/pmc_derived.txt"
 [ -d "$OUT/stats" ] && cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
 true

@@ -52,6 +52,15 @@ def main():
                     der[name] = e[c] / wc
         if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_LDS_IDX_ACTIVE"):
             der["lds_conflict_frac"] = e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"]
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
+            der["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+            if e["duration_ms"]:
+                ms = sum(e["duration_ms"].values()) / len(e["duration_ms"])
+                # 128-byte L2 requests per second (reads and writes) -- an upper bound on bytes moved
+                der["l2_req_128B_TBps"] = e.get("TCC_REQ_sum", 0.0) * 128 / (ms * 1e-3) / 1e12
+        if "SQ_INSTS_VALU" in e and e["duration_ms"]:
+            ms = sum(e["duration_ms"].values()) / len(e["duration_ms"])
+            der["valu_issue_util"] = e["SQ_INSTS_VALU"] / (ms * 1e-3) / 1024 / 1.2e9  # per SIMD, 2 cycles per wave64 op at 2.4 GHz
         if "GRBM_GUI_ACTIVE" in e and e["duration_ms"]:
             ms = sum(e["duration_ms"].values()) / len(e["duration_ms"])
             der["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6)  # the counter sums the 8 XCDs
