@@ -788,12 +788,11 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     a.nprof_total = c->nprof;
     a.nseqs = nq;
     a.q_base = q_begin;
-    // queries a row-sweep wavefront scores one after the other with the profile's transitions in
-    // registers -- fewer when the DB is small: the grid needs some 16k tasks to fill the chip
-    // (25 profiles x 256 queries: 8.8 ms at 8 per task)
-    a.qchunk = nq >= 4096 ? 32u : (nq >= 256 ? 8u : 1u);
-    while (a.qchunk > 1u && (uint64_t)c->nprof * ((nq + a.qchunk - 1u) / a.qchunk) < 16384u)
-        a.qchunk /= 2u;
+    // Queries a row-sweep wavefront scores one after the other with the profile's transitions in registers:
+    // ONE.  More (8 per task in round 1) saves the reload of 8 transitions per node and nothing else, but
+    // leaves fewer concurrent tasks per profile, so that an XCD works on more profiles at a time than its
+    // 4 MB L2 holds tables of (C3 step: 848 -> 879 Gcell/s from 8 to 1; 25 profiles x 256 queries: 8.8 -> 1.8 ms).
+    a.qchunk = 1u;
     a.nchunks = (nq + a.qchunk - 1) / a.qchunk;
     c->last_q0 = q_begin;
     c->last_q1 = q_end;
