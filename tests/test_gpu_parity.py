@@ -624,6 +624,34 @@ def test_long_sequences(dcp, oracle32, scanner, kern):
     assert np.isfinite(ga).all()
 
 
+def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
+    """The reference accepts sequences up to SCHED_SEQ_SIZE = 1 MiB (src/server/scan.c:227-229 reads them into a
+    buffer of that size).  A 300 000-nt query: the automatic choice is the row sweep (the query-lane kernels would
+    keep one lane busy for minutes); forced, the query-lane kernels hold too -- 32-bit row offsets into scratch
+    planes of 300 MB, fewer resident blocks.  All equal the oracle bit for bit."""
+    rng = np.random.default_rng(1 << 20)
+    profiles = make_profiles(dcp, [(301, 40, ENTRY_DIST_OCCUPANCY, 0.01), (302, 120, ENTRY_DIST_OCCUPANCY, 0.01)])
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (300000, 33, 2000)]
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    scanner.scan(True, False, 10.0)
+    assert scanner.last_scan_kernel == dcp.KERNEL_ROWSWEEP
+    for k in (dcp.KERNEL_AUTO, dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2):
+        scanner.scan(True, False, 10.0, kernel=k)
+        gn, ga = scanner.scores()
+        assert same_bits(gn, on) and same_bits(ga, oa), k
+    assert np.isfinite(ga).all()
+    # the limit itself (1 MiB - 1 bases), automatic choice only
+    seqs = [rng.integers(0, 4, (1 << 20) - 1, dtype=np.uint8), rng.integers(0, 4, 77, dtype=np.uint8)]
+    scanner.upload_seqs(seqs)
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
+    scanner.scan(True, False, 10.0)
+    assert scanner.last_scan_kernel == dcp.KERNEL_ROWSWEEP
+    gn, ga = scanner.scores()
+    assert same_bits(gn, on) and same_bits(ga, oa)
+
+
 def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_mod):
     """BASELINE.json's headline size: one bench step = 20 000 profiles (sum M = 3.57e6) x 1 000 queries of
     1 000 nt = 2e7 pairs, 3.6e12 cells.  Too big for the oracle, so a size-independent property: the two
