@@ -624,6 +624,29 @@ def test_long_sequences(dcp, oracle32, scanner, kern):
     assert np.isfinite(ga).all()
 
 
+def test_more_than_65536_profiles(dcp, oracle32, scanner, kern):
+    """Profile indices beyond 16 bits (the reader allows 2^20 profiles per DB, src/db/reader.c): three distinct
+    profiles repeated 22 000 times; every copy's scores equal the oracle's for its original."""
+    rng = np.random.default_rng(65536)
+    base = make_profiles(dcp, [(401, 2, ENTRY_DIST_OCCUPANCY, 0.01), (402, 70, ENTRY_DIST_OCCUPANCY, 0.01),
+                               (403, 300, ENTRY_DIST_UNIFORM, 0.01)])
+    seqs = rand_seqs(rng, 5, 20, 90)
+    scanner.upload_db(base, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, base, seqs, True, False, True)
+    reps = 22000
+    scanner.upload_db(base * reps)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0, kernel=kern)
+    gn, ga = scanner.scores()
+    assert gn.shape == (5, 3 * reps)
+    assert same_bits(gn, np.tile(on, (1, reps))) and same_bits(ga, np.tile(oa, (1, reps)))
+    hits = scanner.hits()
+    want = {(q, p) for q in range(5) for p in range(3) if np.isfinite(-2 * (on[q, p] - oa[q, p])) and not (np.float32(-2) * (on[q, p] - oa[q, p]) < 10.0)}
+    assert {(int(h["seq_idx"]), int(h["profile_idx"]) % 3) for h in hits} == want
+    assert len(hits) == len(want) * reps
+
+
 def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
     """The reference accepts sequences up to SCHED_SEQ_SIZE = 1 MiB (src/server/scan.c:227-229 reads them into a
     buffer of that size).  A 300 000-nt query: the automatic choice is the row sweep (the query-lane kernels would
