@@ -647,6 +647,27 @@ def test_more_than_65536_profiles(dcp, oracle32, scanner, kern):
     assert len(hits) == len(want) * reps
 
 
+def test_more_than_65536_queries(dcp, oracle32, scanner, kern):
+    """Sequence indices beyond 16 bits in one resident batch: 70 000 short queries (1..40 nt), three profiles."""
+    rng = np.random.default_rng(70000)
+    profiles = make_profiles(dcp, [(411, 5, ENTRY_DIST_OCCUPANCY, 0.01), (412, 70, ENTRY_DIST_OCCUPANCY, 0.01),
+                                   (413, 260, ENTRY_DIST_UNIFORM, 0.01)])
+    seqs = rand_seqs(rng, 70000, 1, 40)
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(True, False, 10.0, kernel=kern)
+    gn, ga = scanner.scores()
+    # the oracle on a sample that includes both ends of the batch and the 16-bit boundary
+    idx = sorted(set([0, 1, 65535, 65536, 65537, 69999] + [int(i) for i in rng.integers(0, 70000, 600)]))
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, [seqs[i] for i in idx], True, False, True)
+    assert same_bits(gn[idx], on) and same_bits(ga[idx], oa)
+    # ranged scan of the tail: same bits, hit records carry batch-relative sequence indices
+    scanner.scan(True, False, 10.0, kernel=kern, q_range=(65000, 70000))
+    n2, a2 = scanner.scores()
+    assert same_bits(n2[65000:], gn[65000:]) and same_bits(a2[65000:], ga[65000:])
+    assert all(65000 <= int(h["seq_idx"]) < 70000 for h in scanner.hits())
+
+
 def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
     """The reference accepts sequences up to SCHED_SEQ_SIZE = 1 MiB (src/server/scan.c:227-229 reads them into a
     buffer of that size).  A 300 000-nt query: the automatic choice is the row sweep (the query-lane kernels would
