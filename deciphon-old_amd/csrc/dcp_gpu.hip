@@ -251,6 +251,70 @@ void *dcp_gpu_stream(dcp_gpu_ctx *c) { return (void *)c->stream; }
 unsigned dcp_gpu_db_nprofiles(dcp_gpu_ctx const *c) { return c->nprof; }
 unsigned dcp_gpu_nseqs(dcp_gpu_ctx const *c) { return c->nseqs; }
 
+// Host -> device stream of floats in device order through two pinned buffers (dcp_gpu_db_upload).
+struct StagedUpload
+{
+    static constexpr size_t kCap = (size_t)16 << 20; // floats per buffer (64 MB)
+    dcp_gpu_ctx *c = nullptr;
+    float *dst = nullptr, *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    size_t off = 0, fill = 0;
+    int cur = 0;
+    int begin(dcp_gpu_ctx *ctx, float *device_dst)
+    {
+        c = ctx, dst = device_dst;
+        for (int i = 0; i < 2; ++i)
+        {
+            HIP_TRY(c, hipHostMalloc((void **)&buf[i], kCap * sizeof(float), hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        return DCP_OK;
+    }
+    int flush()
+    {
+        if (fill == 0) return DCP_OK;
+        HIP_TRY(c, hipMemcpyAsync(dst + off, buf[cur], fill * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(ev[cur], c->stream));
+        busy[cur] = true;
+        off += fill, fill = 0, cur ^= 1;
+        if (busy[cur]) // the buffer about to be refilled: its copy must have left it
+        {
+            HIP_TRY(c, hipEventSynchronize(ev[cur]));
+            busy[cur] = false;
+        }
+        return DCP_OK;
+    }
+    int append(float const *src, size_t n)
+    {
+        while (n)
+        {
+            size_t const k = std::min(n, kCap - fill);
+            std::memcpy(buf[cur] + fill, src, k * sizeof(float));
+            fill += k, src += k, n -= k;
+            if (fill == kCap)
+                if (int rc = flush()) return rc;
+        }
+        return DCP_OK;
+    }
+    int finish()
+    {
+        if (int rc = flush()) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        busy[0] = busy[1] = false;
+        return DCP_OK;
+    }
+    ~StagedUpload()
+    {
+        if (c && (busy[0] || busy[1])) (void)hipStreamSynchronize(c->stream);
+        for (int i = 0; i < 2; ++i)
+        {
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // DB upload
 // ---------------------------------------------------------------------------
@@ -440,26 +504,31 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     {
         // dists rows: all match nodes (sorted profile order), then insert dists
         // by pidx, then null dists by pidx
+        // The compact DB (129 floats per node: 1.9 GB for 20k profiles) goes to the device in the order
+        // the rows have there, through two pinned 64 MB buffers: the copy of one overlaps the filling of
+        // the other, and no host-side image of the whole array is built.
         size_t const rows = (size_t)match_rows + 2 * (size_t)nprofiles;
-        std::vector<float> dists(rows * DCP_NDIST), eps(rows);
+        std::vector<float> eps(rows);
+        HIP_TRY(c, c->d_dists.alloc(rows * DCP_NDIST));
+        StagedUpload up;
+        if (int rc = up.begin(c, c->d_dists.p)) return rc;
         for (unsigned i = 0; i < nprofiles; ++i)
         {
             dcp_prof_meta const &m = c->metas[i];
             dcp_profile const *pr = profiles[m.pidx];
-            std::memcpy(&dists[(size_t)dist_row[i] * DCP_NDIST], dcp_profile_match_dist(pr),
-                        sizeof(float) * DCP_NDIST * m.core_size);
+            if (int rc = up.append(dcp_profile_match_dist(pr), (size_t)DCP_NDIST * m.core_size)) return rc;
             std::fill(eps.begin() + dist_row[i], eps.begin() + dist_row[i] + m.core_size,
                       dcp_profile_epsilon(pr));
         }
         for (unsigned p = 0; p < nprofiles; ++p)
         {
-            std::memcpy(&dists[((size_t)match_rows + p) * DCP_NDIST], dcp_profile_insert_dist(profiles[p]),
-                        sizeof(float) * DCP_NDIST);
-            std::memcpy(&dists[((size_t)match_rows + nprofiles + p) * DCP_NDIST],
-                        dcp_profile_null_dist(profiles[p]), sizeof(float) * DCP_NDIST);
+            if (int rc = up.append(dcp_profile_insert_dist(profiles[p]), DCP_NDIST)) return rc;
             eps[(size_t)match_rows + p] = eps[(size_t)match_rows + nprofiles + p] =
                 dcp_profile_epsilon(profiles[p]);
         }
+        for (unsigned p = 0; p < nprofiles; ++p)
+            if (int rc = up.append(dcp_profile_null_dist(profiles[p]), DCP_NDIST)) return rc;
+        if (int rc = up.finish()) return rc;
         std::vector<dcp_expand_tile> tiles;
         for (unsigned i = 0; i < nprofiles; ++i)
         {
@@ -510,10 +579,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
 
         DevBuf<float> &d_dists = c->d_dists, &d_eps = c->d_eps; // kept for the lazy row-sweep layout
         DevBuf<dcp_expand_tile> d_tiles;
-        HIP_TRY(c, d_dists.alloc(dists.size()));
         HIP_TRY(c, d_eps.alloc(eps.size()));
         HIP_TRY(c, d_tiles.alloc(tiles.size()));
-        HIP_TRY(c, hipMemcpy(d_dists.p, dists.data(), dists.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_eps.p, eps.data(), eps.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * sizeof(dcp_expand_tile), hipMemcpyHostToDevice));
         c->rs_tiles.assign(tiles.begin(), tiles.begin() + (long)n_match_tiles);
