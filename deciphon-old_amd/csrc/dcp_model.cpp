@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 namespace
@@ -173,6 +174,15 @@ struct dcp_profile
     std::vector<float> match_dist; // [M][129]
     float null_dist[DCP_NDIST];
     float insert_dist[DCP_NDIST];
+    // exp() of the base and codon probabilities of the null and insert distributions, for dcp_profile_decode:
+    // most steps of a path are flank steps in N / C / J, all decoded against the null distribution, and the 68
+    // exp() calls were two thirds of a decode.  Filled on first use (profiles are read-only once built).
+    struct DecodeExp
+    {
+        double b[4], pc[64];
+    };
+    mutable std::once_flag decode_once;
+    mutable DecodeExp decode_exp[2]; // 0 null, 1 insert
 };
 
 // calculate_occupancy + setup_entry_trans (protein_model.c:258-283,410-439)
@@ -544,9 +554,9 @@ namespace
 // imm frame state: probability of emitting word x (1..5 bases) given base probs b and
 // codon marginals C (5x5x5, index 4 = wildcard) -- the formula of dcp_frame_table_host,
 // evaluated for one word.
-double frame_prob_word(double const *b, double const *C, double e, double f, uint8_t const *x, unsigned len)
+// C3(p, q, r): codon marginal with wildcard index 4 -- a table (below) or computed on the fly (decode)
+template <class C3> double frame_prob_word_of(double const *b, C3 const &c3, double e, double f, uint8_t const *x, unsigned len)
 {
-    auto c3 = [&](int p, int q, int r) { return C[p * 25 + q * 5 + r]; };
     auto s1 = [&](int p) { return c3(p, 4, 4) + c3(4, p, 4) + c3(4, 4, p); };
     auto s2 = [&](int p, int q) { return c3(4, p, q) + c3(p, 4, q) + c3(p, q, 4); };
     double const e2 = e * e, f2 = f * f;
@@ -641,9 +651,24 @@ int dcp_profile_decode(dcp_profile const *p, uint8_t const *frag, unsigned len, 
         return DCP_EINVAL; // mute states emit nothing: assert(!protein_state_is_mute) :310
     else
         dist = p->null_dist;
-    double b[4], full[125];
-    for (int i = 0; i < 4; ++i)
-        b[i] = std::exp((double)dist[i]);
+    auto const fill = [](float const *d, dcp_profile::DecodeExp &x) {
+        for (int i = 0; i < 4; ++i)
+            x.b[i] = std::exp((double)d[i]);
+        for (int a = 0; a < 4; ++a)
+            for (int bb = 0; bb < 4; ++bb)
+                for (int cc = 0; cc < 4; ++cc)
+                    x.pc[a * 16 + bb * 4 + cc] = std::exp((double)d[4 + a * 25 + bb * 5 + cc]);
+    };
+    dcp_profile::DecodeExp own;
+    dcp_profile::DecodeExp const *x = &own;
+    if (dist == p->null_dist || dist == p->insert_dist)
+    {
+        std::call_once(p->decode_once, [&]() { fill(p->null_dist, p->decode_exp[0]), fill(p->insert_dist, p->decode_exp[1]); });
+        x = &p->decode_exp[dist == p->insert_dist];
+    }
+    else
+        fill(dist, own);
+    double const *b = x->b;
     double const e = (double)p->epsilon, f = 1.0 - e;
     double best = -1.0;
     codon[0] = codon[1] = codon[2] = 4;
@@ -651,13 +676,15 @@ int dcp_profile_decode(dcp_profile const *p, uint8_t const *frag, unsigned len, 
         for (int bb = 0; bb < 4; ++bb)
             for (int cc = 0; cc < 4; ++cc)
             {
-                double const pc = std::exp((double)dist[4 + a * 25 + bb * 5 + cc]);
-                for (int i = 0; i < 5; ++i)
-                    for (int j = 0; j < 5; ++j)
-                        for (int k = 0; k < 5; ++k)
-                            full[i * 25 + j * 5 + k] =
-                                ((i == 4 || i == a) && (j == 4 || j == bb) && (k == 4 || k == cc)) ? pc : 0.0;
-                double const v = frame_prob_word(b, full, e, f, frag, len);
+                // the marginal table of "the codon IS (a, bb, cc)": pc where every index is that base or the
+                // wildcard, 0 elsewhere -- read entry by entry instead of being built (125 stores per codon,
+                // 64 codons per decoded step); the sums see the same operands in the same order, so the
+                // arg-max is the one the table gave
+                double const pc = x->pc[a * 16 + bb * 4 + cc];
+                auto const c3 = [&](int i, int j, int k) {
+                    return ((i == 4 || i == a) && (j == 4 || j == bb) && (k == 4 || k == cc)) ? pc : 0.0;
+                };
+                double const v = frame_prob_word_of(b, c3, e, f, frag, len);
                 if (v >= best)
                 {
                     best = v;

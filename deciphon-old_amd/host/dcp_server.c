@@ -120,8 +120,7 @@ void prod_final_cleanup(void) { tmp_del(&final_file); }
 
 /* One products row: eight tab-separated fields, then the match column -- one "frag,state,codon,amino"
  * item per path step, ';'-separated, each written by the caller's fwrite_match (prod.c:13-41,153-181). */
-enum rc prod_fwrite(struct prod const *prod, struct imm_seq const *seq, struct imm_path const *path,
-                    unsigned thread_num, prod_fwrite_match_func_t fwrite_match, struct match *match)
+static enum rc prod_thread_fp(unsigned thread_num, FILE **fp)
 {
     if (thread_num >= NUM_THREADS) return fail(RC_EINVAL, "thread number out of range");
     if (!prod_file[thread_num].fp)
@@ -130,7 +129,24 @@ enum rc prod_fwrite(struct prod const *prod, struct imm_seq const *seq, struct i
         if (tmp_open(prod_file + thread_num)) return fail(RC_EIO, "failed to write prod");
         if (num_threads <= thread_num) num_threads = thread_num + 1;
     }
-    FILE *fp = prod_file[thread_num].fp;
+    *fp = prod_file[thread_num].fp;
+    return RC_OK;
+}
+
+static enum rc prod_fwrite_fp(FILE *fp, struct prod const *prod, struct imm_seq const *seq, struct imm_path const *path,
+                             prod_fwrite_match_func_t fwrite_match, struct match *match);
+
+enum rc prod_fwrite(struct prod const *prod, struct imm_seq const *seq, struct imm_path const *path,
+                    unsigned thread_num, prod_fwrite_match_func_t fwrite_match, struct match *match)
+{
+    FILE *fp = NULL;
+    enum rc rc = prod_thread_fp(thread_num, &fp);
+    return rc ? rc : prod_fwrite_fp(fp, prod, seq, path, fwrite_match, match);
+}
+
+static enum rc prod_fwrite_fp(FILE *fp, struct prod const *prod, struct imm_seq const *seq, struct imm_path const *path,
+                             prod_fwrite_match_func_t fwrite_match, struct match *match)
+{
     if (fprintf(fp, "%" PRId64 "\t%" PRId64 "\t%s\t%s\t%.17g\t%.17g\t%s\t%s\t", prod->scan_id, prod->seq_id,
                 prod->profile_name, prod->abc_name, prod->alt_loglik, prod->null_loglik, prod->profile_typeid,
                 prod->version) < 0)
@@ -374,29 +390,80 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
         if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, hits, nhits, t->multi_hits, t->hmmer3_compat, 0, steps,
                                               (unsigned)cap, soff, NULL)))
             rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
-        for (unsigned h = 0; !rc && h < nhits; ++h)
+        /* Product rows: one per hit, each formatted into its own memory stream -- every emitting step of a
+         * path is decoded against its state's codon distribution, a few hundred per row -- by however many
+         * host threads OpenMP gives this call (none extra when the caller already runs it inside a parallel
+         * region), then appended to the partition's file in hit order: the file is what the serial loop wrote. */
+        char **row = NULL;
+        size_t *row_len = NULL;
+        FILE *out = NULL;
+        if (!rc) rc = prod_thread_fp(t->id, &out);
+        if (!rc)
         {
-            unsigned const q = hits[h].seq_idx;
-            imm_float const lrt = xmath_lrt_f32(hits[h].null_loglik, hits[h].alt_loglik);
-            if (!imm_lprob_is_finite(lrt) || lrt < t->lrt_threshold) continue; /* scan_thread.c:123 */
-            struct protein_profile view;
-            if ((rc = profile_view(t, hits[h].profile_idx, &view))) break;
-            /* strcpy(t->prod.profile_name, prof->accession); match_setup; write_product (:125-128) */
-            snprintf(t->prod.profile_name, sizeof t->prod.profile_name, "%s", view.super.accession);
-            if (seq_ids) t->prod.seq_id = seq_ids[q];
+            row = calloc(nhits, sizeof *row);
+            row_len = calloc(nhits, sizeof *row_len);
+            if (!row || !row_len) rc = fail(RC_ENOMEM, "alloc product rows");
+        }
+        if (!rc)
+        {
+            enum rc shared = RC_OK;
+#pragma omp parallel for schedule(dynamic, 8) if (nhits >= 64)
+            for (unsigned h = 0; h < nhits; ++h)
+            {
+                enum rc cur;
+#pragma omp atomic read
+                cur = shared;
+                if (cur) continue;
+                unsigned const q = hits[h].seq_idx;
+                imm_float const lrt = xmath_lrt_f32(hits[h].null_loglik, hits[h].alt_loglik);
+                if (!imm_lprob_is_finite(lrt) || lrt < t->lrt_threshold) continue; /* scan_thread.c:123 */
+                struct protein_profile view;
+                struct imm_path path = {0};
+                struct protein_match pm;
+                struct prod pr = t->prod; /* job fields; the per-hit ones follow (:125-128) */
+                FILE *ms = NULL;
+                enum rc r = profile_view(t, hits[h].profile_idx, &view);
+                if (!r)
+                {
+                    snprintf(pr.profile_name, sizeof pr.profile_name, "%s", view.super.accession);
+                    if (seq_ids) pr.seq_id = seq_ids[q];
+                    pr.null_loglik = (double)hits[h].null_loglik;
+                    pr.alt_loglik = (double)hits[h].alt_loglik;
+                    r = dcp_host_path_assign(&path, steps + soff[h], soff[h + 1] - soff[h]);
+                    if (!r && !(ms = open_memstream(&row[h], &row_len[h]))) r = fail(RC_ENOMEM, "alloc product row");
+                    if (!r)
+                    {
+                        match_setup(&pm.match, &view.super);
+                        r = prod_fwrite_fp(ms, &pr, &seqs[q], &path, t->write_match_func, &pm.match);
+                    }
+                    if (ms && fclose(ms) && !r) r = fail(RC_EIO, "failed to write prod");
+                    free(view.alt.match_ndists);
+                }
+                free(path.steps);
+                if (r)
+                {
+#pragma omp atomic write
+                    shared = r;
+                }
+            }
+            rc = shared;
+        }
+        for (unsigned h = 0; row && h < nhits; ++h)
+        {
+            if (!rc && row[h] && row_len && fwrite(row[h], 1, row_len[h], out) != row_len[h]) rc = fail(RC_EIO, "failed to write prod");
+            free(row[h]);
+        }
+        free(row);
+        free(row_len);
+        /* the thread's own prod / match keep what the serial loop left in them: the last hit's fields */
+        if (!rc && nhits)
+        {
+            unsigned const h = nhits - 1u;
             t->prod.null_loglik = (double)hits[h].null_loglik;
             t->prod.alt_loglik = (double)hits[h].alt_loglik;
             t->null.prod.loglik = hits[h].null_loglik;
             t->alt.prod.loglik = hits[h].alt_loglik;
-            rc = dcp_host_path_assign(&t->alt.prod.path, steps + soff[h], soff[h + 1] - soff[h]);
-            if (!rc)
-            {
-                match_setup((struct match *)&t->match, &view.super);
-                rc = prod_fwrite(&t->prod, &seqs[q], &t->alt.prod.path, t->id, t->write_match_func,
-                                 (struct match *)&t->match);
-                t->match.pro.match.profile = NULL; /* the view dies here */
-            }
-            free(view.alt.match_ndists);
+            if (seq_ids) t->prod.seq_id = seq_ids[hits[h].seq_idx];
         }
     }
     free(soff);

@@ -5,7 +5,7 @@
  *
  *   gcc -std=gnu11 -O2 -I include profiles/host_scan_probe.c -o /tmp/host_scan_probe \
  *       -L deciphon-old_amd -ldeciphon_host -ldcp_hip -lm -fopenmp -Wl,-rpath,$PWD/deciphon-old_amd
- *   /tmp/host_scan_probe [nprofiles=2000] [nseqs=2000] [seq_len=1000] [batch=1000]
+ *   /tmp/host_scan_probe [nprofiles=2000] [nseqs=2000] [seq_len=1000] [batch=1000] [lrt_threshold=10]
  *
  * Core sizes: the lognormal draw of BASELINE config C3 restated with this file's own generator (median 150,
  * sigma 0.6, clipped to 30..2000); sequences uniform over ACGT.  Prints one line per phase. */
@@ -39,6 +39,7 @@ int main(int argc, char **argv)
     unsigned const nseqs = argc > 2 ? (unsigned)atoi(argv[2]) : 2000u;
     unsigned const len = argc > 3 ? (unsigned)atoi(argv[3]) : 1000u;
     unsigned const batch = argc > 4 ? (unsigned)atoi(argv[4]) : 1000u;
+    double const threshold = argc > 5 ? atof(argv[5]) : 10.0; /* 1e30: no hits, i.e. no traceback and no product rows */
 
     struct imm_nuclt const *nuclt = imm_super(&imm_dna_iupac);
     struct imm_nuclt_code code;
@@ -114,7 +115,7 @@ int main(int argc, char **argv)
     {
         FILE *prods = tmpfile();
         t0 = now();
-        enum rc rc = scan_run_local(path, seqs, nseqs, 1, true, false, 10.0, 1, batch, prods);
+        enum rc rc = scan_run_local(path, seqs, nseqs, 1, true, false, threshold, 1, batch, prods);
         double const dt = now() - t0;
         if (rc != RC_OK) return fprintf(stderr, "scan_run_local: rc %d\n", (int)rc), 6;
         long rows = -1; /* header line */
