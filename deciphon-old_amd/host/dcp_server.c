@@ -13,6 +13,7 @@
 #include <inttypes.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #define fail dcp_host_fail
@@ -481,6 +482,45 @@ enum rc thread_run(struct scan_thread *t, int tid)
 }
 
 /* ============================== scan loop (src/server/scan.c:215-269) ========================== */
+/* The resident database a scan with cfg.keep_resident left behind (one scan at a time per process, as in the
+ * reference: scan.c:41-43 keeps its state in file-scope statics too). */
+static struct
+{
+    bool valid;
+    dev_t dev;
+    ino_t ino;
+    off_t size;
+    struct timespec mtime;
+    unsigned nparts;
+    bool by_cells;
+    struct
+    {
+        dcp_gpu_ctx *gpu;
+        dcp_profile **impls;
+        unsigned nimpls;
+    } part[NUM_THREADS];
+} g_resident;
+
+void scan_resident_release(void)
+{
+    if (!g_resident.valid) return;
+    for (unsigned i = 0; i < g_resident.nparts; ++i)
+    {
+        if (g_resident.part[i].gpu) dcp_gpu_ctx_del(g_resident.part[i].gpu);
+        for (unsigned k = 0; k < g_resident.part[i].nimpls; ++k)
+            dcp_profile_del(g_resident.part[i].impls[k]);
+        free(g_resident.part[i].impls);
+    }
+    memset(&g_resident, 0, sizeof g_resident);
+}
+
+static bool resident_matches(struct stat const *st, unsigned nparts, bool by_cells)
+{
+    return g_resident.valid && g_resident.dev == st->st_dev && g_resident.ino == st->st_ino &&
+           g_resident.size == st->st_size && g_resident.mtime.tv_sec == st->st_mtim.tv_sec &&
+           g_resident.mtime.tv_nsec == st->st_mtim.tv_nsec && g_resident.nparts == nparts && g_resident.by_cells == by_cells;
+}
+
 enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned nthreads, scan_next_seq_func_t next_seq,
                         void *arg)
 {
@@ -497,7 +537,8 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     struct imm_seq *bseq = NULL;
     int64_t *bid = NULL;
     char **btext = NULL;
-    bool db_open = false, reader_open = false;
+    bool db_open = false, reader_open = false, have_stat = false;
+    struct stat st;
     unsigned nparts = 0;
     enum rc rc = RC_OK;
     if (!db || !reader)
@@ -529,6 +570,30 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
         thread_init(&th[i], i, reader, cfg.multi_hits, cfg.hmmer3_compat, cfg.lrt_threshold, protein_match_write_func);
         thread_setup_job(&th[i], imm_abc_typeid(abc), reader->profile_typeid, cfg.scan_id);
     }
+    have_stat = fstat(fileno(fp), &st) == 0;
+    if (have_stat && resident_matches(&st, nparts, cfg.balance_by_cells))
+    {
+        /* the previous scan's resident partitions: theirs to this scan's threads (thread_prepare finds
+         * db_resident set and goes straight to the sequences) */
+        for (unsigned i = 0; i < nparts; ++i)
+        {
+            th[i].gpu = g_resident.part[i].gpu;
+            th[i].impls = g_resident.part[i].impls;
+            th[i].nimpls = g_resident.part[i].nimpls;
+            th[i].db_resident = th[i].gpu != NULL && th[i].nimpls == reader->partition_size[i];
+            if (!th[i].db_resident && th[i].gpu) /* never expected: fall back to a fresh load */
+            {
+                dcp_gpu_ctx_del(th[i].gpu);
+                for (unsigned k = 0; k < th[i].nimpls; ++k)
+                    dcp_profile_del(th[i].impls[k]);
+                free(th[i].impls);
+                th[i].gpu = NULL, th[i].impls = NULL, th[i].nimpls = 0;
+            }
+        }
+        memset(&g_resident, 0, sizeof g_resident);
+    }
+    else
+        scan_resident_release(); /* another database (or layout): its memory goes first */
 
     for (bool more = true; more && !rc;)
     {
@@ -578,6 +643,26 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
 
 cleanup:
     if (rc) prod_fcleanup();
+    if (!rc && cfg.keep_resident && th && have_stat && nparts > 0)
+    {
+        bool all = true;
+        for (unsigned i = 0; i < nparts; ++i)
+            all = all && th[i].db_resident;
+        if (all)
+        {
+            g_resident.valid = true;
+            g_resident.dev = st.st_dev, g_resident.ino = st.st_ino, g_resident.size = st.st_size;
+            g_resident.mtime = st.st_mtim;
+            g_resident.nparts = nparts, g_resident.by_cells = cfg.balance_by_cells;
+            for (unsigned i = 0; i < nparts; ++i)
+            {
+                g_resident.part[i].gpu = th[i].gpu;
+                g_resident.part[i].impls = th[i].impls;
+                g_resident.part[i].nimpls = th[i].nimpls;
+                th[i].gpu = NULL, th[i].impls = NULL, th[i].nimpls = 0; /* thread_cleanup leaves them alone */
+            }
+        }
+    }
     for (unsigned i = 0; th && i < nparts; ++i)
         thread_cleanup(&th[i]);
     for (unsigned i = 0; btext && i < batch; ++i)
@@ -610,7 +695,7 @@ enum rc scan_run_local(char const *db_filename, struct scan_seq const *seqs, uns
 {
     if (!seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
     struct list_source src = {seqs, nseqs, 0};
-    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true};
+    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true, false};
     enum rc rc = scan_run_source(db_filename, cfg, nthreads, list_next, &src);
     if (rc) return rc;
     char buf[1 << 16];

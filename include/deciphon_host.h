@@ -844,7 +844,14 @@ struct scan_cfg
     double lrt_threshold;  /* scan.c:221 passes 10.0 */
     unsigned batch;        /* sequences per device pass; 0 = 1 */
     bool balance_by_cells; /* partitions by profile bytes (one per GPU) instead of by count */
+    /* Leave the database resident (device contexts + unpacked profiles of every partition) when the scan
+     * ends: the next scan_run_source of the SAME file (device, inode, size, mtime), partition count and
+     * balance picks it up and skips unpacking and upload -- what a server that polls jobs in one process
+     * wants (20k profiles: 1.5 s per job).  Device memory stays allocated until scan_resident_release()
+     * or a scan of another database. */
+    bool keep_resident;
 };
+void scan_resident_release(void);
 enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned num_threads,
                         scan_next_seq_func_t next_seq, void *arg);
 /* scan_run_source over an in-memory sequence list, products copied to `prods`. */

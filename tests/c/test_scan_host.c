@@ -385,6 +385,61 @@ static unsigned split_lines(char *text, char **lines, unsigned cap)
     return n;
 }
 
+/* cfg.keep_resident: the next scan of the same file picks the resident partitions up (no unpack, no upload)
+ * and writes the same products; a scan of a different layout, or scan_resident_release(), drops them. */
+struct list_src
+{
+    struct scan_seq const *seqs;
+    unsigned n, at;
+};
+static enum rc list_src_next(void *arg, struct scan_seq *seq)
+{
+    struct list_src *l = arg;
+    if (l->at == l->n) return RC_END;
+    *seq = l->seqs[l->at++];
+    return RC_OK;
+}
+static char *run_source(struct scan_seq const *seqs, unsigned n, unsigned nthreads, bool keep)
+{
+    struct list_src src = {seqs, n, 0};
+    struct scan_cfg cfg = {.scan_id = 9, .multi_hits = true, .hmmer3_compat = false, .lrt_threshold = 10.0, .batch = 3,
+                           .balance_by_cells = true, .keep_resident = keep};
+    CHECK(scan_run_source(g_db_path, cfg, nthreads, list_src_next, &src) == RC_OK);
+    char *text = slurp(prod_final_fp());
+    prod_final_cleanup();
+    return text;
+}
+static void resident_reuse(void)
+{
+    enum { NSEQ = 4 };
+    char text[NSEQ][512];
+    struct scan_seq seqs[NSEQ];
+    for (unsigned q = 0; q < NSEQ; ++q)
+    {
+        snprintf(text[q], sizeof text[q], "GATTACA%sTTGACCAGG", q == 1 ? g_domain[2] : q == 3 ? g_domain[0] : "ACGT");
+        seqs[q] = (struct scan_seq){500 + q, text[q]};
+    }
+    char *fresh = run_source(seqs, NSEQ, 2, false);
+    char *first = run_source(seqs, NSEQ, 2, true);   /* loads, leaves resident */
+    char *again = run_source(seqs, NSEQ, 2, true);   /* picks up */
+    char *other = run_source(seqs, NSEQ, 1, true);   /* another partition count: reloads */
+    char *third = run_source(seqs + 1, NSEQ - 1, 1, false); /* picks up, does not keep */
+    scan_resident_release();                         /* nothing left: a no-op */
+    CHECK(strcmp(fresh, first) == 0 && strcmp(fresh, again) == 0);
+    CHECK(strstr(fresh, "\tPF00002\t") != NULL && strstr(fresh, "\tPF00000\t") != NULL);
+    /* one partition: the same rows (one thread's file instead of two joined) */
+    char *a[64], *b[64];
+    unsigned na = split_lines(fresh + strlen(prod_header()), a, 64), nb = split_lines(other + strlen(prod_header()), b, 64);
+    CHECK(na == nb && na >= 2);
+    unsigned same = 0;
+    for (unsigned i = 0; i < na; ++i)
+        for (unsigned k = 0; k < nb; ++k)
+            same += strcmp(a[i], b[k]) == 0;
+    CHECK(same == na);
+    CHECK(strstr(third, "9\t500\t") == NULL && strstr(third, "9\t501\t") != NULL);
+    free(fresh), free(first), free(again), free(other), free(third);
+}
+
 static void scan_run_batched(void)
 {
     enum { NSEQ = 7 };
@@ -606,6 +661,7 @@ int main(void)
     press_db();
     scan_threads();
     scan_run_batched();
+    resident_reuse();
     remove(g_db_path);
     one_process_per_gpu();
     concurrent_viterbi();
