@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both command shapes work for N > 1: under torch.distributed.run every process is one rank (RANK /
+LOCAL_RANK / WORLD_SIZE from the environment); started plainly, `python bench.py --gpus N` starts its
+own N rank processes (children created before anything in this process touches the GPU, rendezvous
+on 127.0.0.1), passes rank 0's JSON line through and exits with the children's return code.
+
 Workload (config.workload): BASELINE.json configs[2] "Pfam-A-like 20k protein profiles x
 1 kbp queries": 20 000 sampled profiles (protein_profile_sample semantics, seeds 0xDEC1F0+p,
 core sizes clip(round(exp(N(ln 150, 0.6^2))), 30, 2000), seed 20000, OCCUPANCY entry, eps 0.01),
@@ -179,20 +184,131 @@ def parity_sample(dcp, sc, sizes, shard_begin, qlen, q_range, nsample=48):
 
     orc = Oracle(32)
     q0, q1 = q_range[0], min(q_range[1], q_range[0] + 8)
-    sc.scan(True, False, 10.0, keep_scores=True, sync=True, q_range=(q0, q1))
+    batch = make_queries(q0, q1, qlen)  # the first queries of the first timed step, uploaded again
+    sc.upload_seqs([np.ascontiguousarray(x) for x in batch])
+    sc.scan(True, False, 10.0, keep_scores=True, sync=True)
     nl, al = sc.scores()
     rng = np.random.default_rng(12345)
     worst, n = 0.0, 0
-    queries = {q: bytes(make_queries(q, q + 1, qlen)[0]) for q in range(q0, q1)}
+    queries = {q: bytes(batch[q - q0]) for q in range(q0, q1)}
     for _ in range(nsample):
         q = int(rng.integers(q0, q1))
         p = int(rng.integers(0, sc.nprofiles))
         op = orc.sample(0xDEC1F0 + shard_begin + p, int(sizes[shard_begin + p]))
         op.setup(len(queries[q]), True, False)
         _, on, oa = op.viterbi_fast(queries[q])
-        worst = max(worst, abs(nl[q, p] - on) / abs(on), abs(al[q, p] - oa) / abs(oa))
+        worst = max(worst, abs(nl[q - q0, p] - on) / abs(on), abs(al[q - q0, p] - oa) / abs(oa))
         n += 1
     return {"pairs": n, "max_rel_err_vs_oracle": float("%.3g" % worst), "tolerance": 5e-5, "ok": bool(worst <= 5e-5)}
+
+
+def self_launch(argv, ngpus, grace_s=20.0):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.
+
+    The parent never touches the GPU (it imports neither torch nor the product library): the ranks are
+    plain child processes -- never an exec of a process that initialised HIP -- with RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT in their environment, exactly what
+    torch.distributed.run would give them.  Rank 0 inherits stdout (its one JSON line is the parent's
+    output), the other ranks' stdout goes to stderr.  Returns the first non-zero child return code (a
+    failed rank leaves the others blocked in a collective: they are given `grace_s`, then terminated by PID)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   DCP_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, deadline = 0, None
+    alive = list(procs)
+    while alive:
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                deadline = time.monotonic() + grace_s
+        if deadline is not None and alive and time.monotonic() > deadline:
+            for pr in alive:
+                pr.terminate()  # exactly the PIDs started above
+            for pr in alive:
+                try:
+                    pr.wait(10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def stub_rank(args, rank, world):
+    """--stub-scan (tests/test_bench_launcher.py only): the N > 1 plumbing of this file on a box WITHOUT a
+    GPU -- rank bootstrap on gloo, the shard map, the per-step hit gather through the same
+    dcp_dist_merge_hits bookkeeping, max-over-ranks timing, one JSON line from rank 0, return codes --
+    with the scan itself replaced by fabricated hit records.  It measures nothing and says so."""
+    import torch
+    import torch.distributed as dist
+
+    load_product()
+    from deciphon_old_amd import dist as ddist
+    from deciphon_old_amd import HIT_DTYPE
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = WORKLOADS[args.workload]
+    nprof = args.nprof or wl["nprof"]
+    qstep = (args.qstep or wl["qstep"]) * world
+    sizes = core_sizes_for(args.workload, nprof)
+    b, e = ddist.shard_range(sizes, world, rank)
+    if args.stub_fail_rank == rank:
+        sys.exit(7)  # rc propagation through the launcher
+    cap = 64
+    words = torch.zeros((cap, 4), dtype=torch.int32)
+    count = torch.zeros(1, dtype=torch.int32)
+    seen = 0
+
+    def step(i):
+        nonlocal seen
+        n = (i + rank) % 5  # this rank's fabricated hits of step i: shard-local profile indices
+        rec = np.zeros(n, HIT_DTYPE)
+        rec["seq_idx"] = (np.arange(n) * 7 + i) % qstep
+        rec["profile_idx"] = (np.arange(n) * 13 + rank) % max(1, e - b)
+        rec["null_loglik"], rec["alt_loglik"] = -100.0, -90.0
+        words.zero_()
+        if n:
+            words[:n] = torch.from_numpy(rec.view(np.int32).reshape(n, 4))
+        count[0] = n
+        h = ddist.gather_hits(words, count, b)
+        assert len(h) == sum((i + r) % 5 for r in range(world))
+        assert (np.diff(h["seq_idx"].astype(np.int64)) >= 0).all() and (h["profile_idx"] < nprof).all()
+        seen += len(h)
+
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    bounds = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(bounds, torch.tensor([b, e]))
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (launcher test: no scan ran, nothing was measured)", "value": 0.0,
+                          "unit": "Gcell/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 3),
+                          "stub": True, "transport": "gloo + dcp_dist_merge_hits",
+                          "shards": [[int(x) for x in t] for t in bounds], "hits_gathered": seen,
+                          "self_launched": os.environ.get("DCP_BENCH_SELF_LAUNCHED") == "1"}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -216,15 +332,24 @@ def main():
     ap.add_argument("--dense-random", action="store_true")
     ap.add_argument("--planted", action="store_true",
                     help="planted-hit variant: 1 %% of the queries carry a real hit (exercises hits / gather)")
+    ap.add_argument("--e2e-steps", type=int, default=-1,
+                    help="steps of the end-to-end leg (each step uploads its own sequences, scans, fetches the hits "
+                         "to the host); default min(steps, 5), 0 = skip")
+    ap.add_argument("--stub-scan", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU (gloo)
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-grace", type=float, default=20.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only starts and reaps the N ranks
+        sys.exit(self_launch(sys.argv[1:], args.gpus, args.launch_grace))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.stub_scan:
+        return stub_rank(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -288,6 +413,11 @@ def main():
         sc.upload_seqs_flat(queries.reshape(-1), off)
     else:
         sc.upload_seqs(queries)
+    # the end-to-end leg re-uploads the batches of the first timed steps from these host copies
+    n_e2e = (min(args.steps, 5) if args.e2e_steps < 0 else min(args.e2e_steps, args.steps)) if not args.dense else 0
+    e2e_batches = [queries[i * qstep:(i + 1) * qstep] for i in range(args.warmup, args.warmup + n_e2e)]
+    if qlen:
+        e2e_batches = [np.ascontiguousarray(x) for x in e2e_batches]
     del queries
 
     cap = 1 << 16
@@ -389,6 +519,49 @@ def main():
     elapsed = time.perf_counter() - t0
 
     cells_rank = float(sum(v["cells"] for v in per_class.values()))
+
+    # ---- end-to-end leg (SURVEY 8d "kernel-only AND end-to-end"): nothing of a step is resident but the DB.
+    # Each step hands its own host sequences to the boundary (dcp_gpu_seqs_upload: H2D, 2-bit packing, the
+    # 13 length-dependent transitions per query), scans them against the whole shard, and brings the hit
+    # list back to the host (N = 1: D2H of the records; N > 1: the RCCL gather, which ends on the host).
+    e2e = None
+    if n_e2e:
+        def e2e_step(k):
+            batch = e2e_batches[k]
+            if qlen:
+                sc.upload_seqs_flat(batch.reshape(-1), (np.arange(len(batch) + 1, dtype=np.uint64) * qlen).astype(np.uint32))
+            else:
+                sc.upload_seqs(batch)
+            sc.scan(True, False, 10.0, keep_scores=False, sync=False, kernel=kernel_id)
+            sc.sync()
+            if cdist_state["comm"]:
+                h, _ = cdist_state["comm"].gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
+            elif world > 1 or force_dist:
+                h = ddist.gather_hits(hit_words, hit_count, b)
+            else:
+                h = hit_words[:min(cap, int(hit_count.item()))].cpu().numpy()
+            return len(h) if h is not None else 0
+
+        e2e_step(0)  # untimed: the sequence buffers are re-sized to one step's batch
+        fence()
+        t0 = time.perf_counter()
+        e2e_hits = sum(e2e_step(k) for k in range(n_e2e))
+        fence()
+        e2e_elapsed = time.perf_counter() - t0
+        e2e_cells = cells_rank / args.steps * n_e2e
+        if world > 1:
+            tt = torch.tensor([e2e_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cc = torch.tensor([e2e_cells], dtype=torch.float64, device="cuda")
+            dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+            e2e_elapsed, e2e_cells = float(tt.item()), float(cc.item())
+        e2e = {"value": round(e2e_cells / e2e_elapsed / 1e9, 3), "unit": "Gcell/s",
+               "ms_per_step": round(e2e_elapsed / n_e2e * 1e3, 3), "steps": n_e2e,
+               "seqs_per_sec": round(n_e2e * qstep / e2e_elapsed, 2), "hits_fetched": int(e2e_hits),
+               "what": "per step: host sequences -> dcp_gpu_seqs_upload (H2D + pack + per-query transitions) -> "
+                       "scan of the whole resident DB shard -> hit records on the host"
+                       + (" through the hit gather" if (world > 1 or force_dist) else " (D2H)")
+                       + "; the batches are those of the first timed steps of the resident leg"}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -520,6 +693,7 @@ def main():
                 "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({cdist_state['kind']})" if (world > 1 or force_dist) else ""),
             },
             "roofline": roof,
+            "e2e": e2e,
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
             # every DCP_* variable in the environment (the library reads none of them; bench.py reads
             # DCP_BENCH_FORCE_DIST only)
