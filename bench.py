@@ -466,7 +466,7 @@ def main():
                 kernel=kernel_id)
         sc.sync()
         if cdist_state["comm"]:
-            h, total = cdist_state["comm"].gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
+            h, total = cdist_state["comm"].gather_scan_hits(sc, b)
             if i < args.warmup:
                 # untimed cross-check of the C gather against the torch.distributed transport, record for record;
                 # every rank takes the same decision, and a mismatch demotes the run to the torch transport
@@ -535,7 +535,7 @@ def main():
             sc.scan(True, False, 10.0, keep_scores=False, sync=False, kernel=kernel_id)
             sc.sync()
             if cdist_state["comm"]:
-                h, _ = cdist_state["comm"].gather_hits(hit_words.data_ptr(), hit_count.data_ptr(), cap, b, sc.stream)
+                h, _ = cdist_state["comm"].gather_scan_hits(sc, b)
             elif world > 1 or force_dist:
                 h = ddist.gather_hits(hit_words, hit_count, b)
             else:

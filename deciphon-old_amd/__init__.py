@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "dcp_profile_from_parts", "dcp_profile_entry_dist", "dcp_profile_epsilon", "dcp_rnd_seed", "dcp_rnd_next",
     "dcp_dist_unique_id", "dcp_dist_init", "dcp_dist_init_from_file", "dcp_dist_free", "dcp_dist_rank",
     "dcp_dist_nranks", "dcp_dist_last_error", "dcp_dist_shard", "dcp_dist_gather_hits", "dcp_dist_free_hits",
-    "dcp_dist_merge_hits",
+    "dcp_dist_merge_hits", "dcp_dist_gather_scan_hits", "dcp_dist_gather_plan",
     "dcp_lprob_normalize", "dcp_h3reader_open_fp", "dcp_h3reader_next_params", "dcp_gpu_seqs_set_xtrans",
     "dcp_profile_accession", "dcp_profile_trans8", "dcp_profile_null_dist",
     "dcp_profile_insert_dist", "dcp_profile_match_dist", "dcp_frame_table_host", "dcp_xtrans",
@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "dcp_gpu_ctx_new", "dcp_gpu_ctx_del", "dcp_gpu_last_error", "dcp_gpu_stream",
     "dcp_gpu_db_upload", "dcp_gpu_db_nprofiles", "dcp_gpu_db_fetch_match_table",
     "dcp_gpu_seqs_upload", "dcp_gpu_seqs_upload_text", "dcp_gpu_nseqs", "dcp_gpu_scan",
-    "dcp_gpu_sync", "dcp_gpu_test_set_redo_cap", "dcp_gpu_last_scan_kernel", "dcp_gpu_hit_buffer", "dcp_gpu_last_scan_redo_pairs", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
+    "dcp_gpu_sync", "dcp_gpu_last_scan_kernel", "dcp_gpu_hit_buffer", "dcp_gpu_last_scan_redo_pairs", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
     "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
     "dcp_gpu_last_scan_launch_info", "dcp_gpu_scan_cells", "dcp_gpu_scan_algorithmic_bytes",
     "dcp_gpu_trace_paths", "dcp_state_name", "dcp_profile_decode", "dcp_gc_decode",
@@ -104,12 +104,13 @@ HIT_DTYPE = np.dtype([("seq_idx", np.uint32), ("profile_idx", np.uint32),
                       ("null_loglik", np.float32), ("alt_loglik", np.float32)])
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
+def _load(path=None, hooks=False):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C deciphon-old_amd/csrc` (there is no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P, F, U, I = C.c_void_p, C.c_float, C.c_uint, C.c_int
     sig = {
         "dcp_profile_new": (P, [C.c_char_p, U, I, F, P, P, P, C.c_char_p, C.POINTER(I)]),
@@ -140,7 +141,6 @@ def _load():
         "dcp_gpu_seqs_set_xtrans": (I, [P, P, U]),
         "dcp_gpu_scan": (I, [P, C.POINTER(ScanParams)]),
         "dcp_gpu_sync": (I, [P]),
-        "dcp_gpu_test_set_redo_cap": (I, [P, U]),
         "dcp_gpu_last_scan_redo_pairs": (I, [P, C.POINTER(U)]),
         "dcp_gpu_last_scan_ms": (F, [P]),
         "dcp_gpu_last_scan_launches": (U, [P]),
@@ -175,6 +175,8 @@ def _load():
         "dcp_gpu_scan_cells": (C.c_uint64, [P]),
         "dcp_gpu_scan_algorithmic_bytes": (C.c_uint64, [P]),
     }
+    if hooks:
+        sig["dcp_gpu_test_set_redo_cap"] = (I, [P, U])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -183,6 +185,13 @@ def _load():
 
 
 lib = _load()
+TESTHOOKS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libdcp_hip_testhooks.so")
+
+
+def load_testhooks():
+    """TESTS ONLY: the -DDCP_TEST_HOOKS build of the same sources (csrc/Makefile), which adds
+    dcp_gpu_test_set_redo_cap.  `Scanner(device, lib=load_testhooks())` runs a context of that build."""
+    return _load(TESTHOOKS_LIB_PATH, hooks=True)
 
 
 def _f32(a):
@@ -455,8 +464,9 @@ class Scanner:
     """One device context = one reference "partition" (thread_run's unit, scan.c:239-249):
     holds a profile shard resident in HBM and scans sequence batches against it."""
 
-    def __init__(self, device=0):
-        self._c = lib.dcp_gpu_ctx_new(device)
+    def __init__(self, device=0, lib=None):
+        self._lib = lib or globals()["lib"]
+        self._c = self._lib.dcp_gpu_ctx_new(device)
         if not self._c:
             raise DcpError(RC_EFAIL, f"no HIP device {device}: this engine has no CPU fallback")
         self._profiles = None
@@ -464,35 +474,35 @@ class Scanner:
     def close(self):
         c, self._c = getattr(self, "_c", None), None
         if c:
-            lib.dcp_gpu_ctx_del(c)
+            self._lib.dcp_gpu_ctx_del(c)
 
     __del__ = close
 
     def _check(self, rc):
         if rc:
-            raise DcpError(rc, lib.dcp_gpu_last_error(self._c).decode())
+            raise DcpError(rc, self._lib.dcp_gpu_last_error(self._c).decode())
 
     @property
     def stream(self):
-        return lib.dcp_gpu_stream(self._c)
+        return self._lib.dcp_gpu_stream(self._c)
 
     def upload_db(self, profiles, expand_on_host=False):
         arr = (C.c_void_p * len(profiles))(*[p._h for p in profiles])
-        self._check(lib.dcp_gpu_db_upload(self._c, arr, len(profiles), int(expand_on_host)))
+        self._check(self._lib.dcp_gpu_db_upload(self._c, arr, len(profiles), int(expand_on_host)))
         self._profiles = list(profiles)
 
     @property
     def nprofiles(self):
-        return lib.dcp_gpu_db_nprofiles(self._c)
+        return self._lib.dcp_gpu_db_nprofiles(self._c)
 
     @property
     def nseqs(self):
-        return lib.dcp_gpu_nseqs(self._c)
+        return self._lib.dcp_gpu_nseqs(self._c)
 
     def match_table(self, p):
         M = self._profiles[p].core_size
         out = np.zeros((NCODES, M), np.float32)
-        self._check(lib.dcp_gpu_db_fetch_match_table(self._c, p, out.ctypes.data))
+        self._check(self._lib.dcp_gpu_db_fetch_match_table(self._c, p, out.ctypes.data))
         return out
 
     def upload_seqs(self, seqs):
@@ -510,79 +520,80 @@ class Scanner:
     def upload_seqs_flat(self, cat, off):
         cat = np.ascontiguousarray(cat, np.uint8)
         off = np.ascontiguousarray(off, np.uint32)
-        self._check(lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
+        self._check(self._lib.dcp_gpu_seqs_upload(self._c, cat.ctypes.data, off.ctypes.data, len(off) - 1))
         self._seq_lens = np.diff(off.astype(np.int64))
 
     def set_xtrans(self, xt):
         """Explicit special transitions [nseqs, 13] for the resident sequences (dcp_gpu_seqs_set_xtrans):
         what imm_dp_viterbi uses for a profile whose transitions were not set from the sequence length."""
         xt = np.ascontiguousarray(xt, np.float32).reshape(-1, NXTRANS)
-        self._check(lib.dcp_gpu_seqs_set_xtrans(self._c, xt.ctypes.data, len(xt)))
+        self._check(self._lib.dcp_gpu_seqs_set_xtrans(self._c, xt.ctypes.data, len(xt)))
 
     def scan(self, multi_hits=True, hmmer3_compat=False, lrt_threshold=10.0, keep_scores=True,
              sync=True, q_range=None, kernel=KERNEL_AUTO):
         prm = ScanParams(int(multi_hits), int(hmmer3_compat), float(lrt_threshold), int(keep_scores),
                          int(kernel))
         if q_range is None:
-            self._check(lib.dcp_gpu_scan(self._c, C.byref(prm)))
+            self._check(self._lib.dcp_gpu_scan(self._c, C.byref(prm)))
         else:
-            self._check(lib.dcp_gpu_scan_range(self._c, C.byref(prm), q_range[0], q_range[1]))
+            self._check(self._lib.dcp_gpu_scan_range(self._c, C.byref(prm), q_range[0], q_range[1]))
         if sync:
             self.sync()
 
     def set_hit_buffer(self, hits_dev_ptr, cap, nhits_dev_ptr):
         """Route hit records into caller-owned device memory (e.g. a torch tensor for RCCL)."""
-        self._check(lib.dcp_gpu_set_hit_buffer(self._c, hits_dev_ptr, cap, nhits_dev_ptr))
+        self._check(self._lib.dcp_gpu_set_hit_buffer(self._c, hits_dev_ptr, cap, nhits_dev_ptr))
 
     def launch_infos(self):
         out = []
         for i in range(self.last_scan_launches):
             li = LaunchInfo()
-            self._check(lib.dcp_gpu_last_scan_launch_info(self._c, i, C.byref(li)))
+            self._check(self._lib.dcp_gpu_last_scan_launch_info(self._c, i, C.byref(li)))
             out.append(dict(R=li.nodes_per_lane, W=li.waves_per_pair, nprofiles=li.nprofiles,
                             ms=li.ms, cells=li.cells, algorithmic_bytes=li.algorithmic_bytes))
         return out
 
     def sync(self):
-        self._check(lib.dcp_gpu_sync(self._c))
+        self._check(self._lib.dcp_gpu_sync(self._c))
 
     def test_set_redo_cap(self, cap):
-        """TEST-ONLY: shrink the redo lists (0 restores 2^26) to reach the overflow path."""
-        self._check(lib.dcp_gpu_test_set_redo_cap(self._c, int(cap)))
+        """TEST-ONLY, and only on a Scanner of the test-hooks build (load_testhooks): shrink the redo lists
+        (0 restores 2^26) to reach the overflow path."""
+        self._check(self._lib.dcp_gpu_test_set_redo_cap(self._c, int(cap)))
 
     @property
     def last_scan_ms(self):
-        return lib.dcp_gpu_last_scan_ms(self._c)
+        return self._lib.dcp_gpu_last_scan_ms(self._c)
 
     @property
     def last_scan_kernel(self):
         """KERNEL_ROWSWEEP / KERNEL_QLANE / KERNEL_QLANE2: what the last scan ran with."""
-        return lib.dcp_gpu_last_scan_kernel(self._c)
+        return self._lib.dcp_gpu_last_scan_kernel(self._c)
 
     @property
     def last_scan_launches(self):
-        return lib.dcp_gpu_last_scan_launches(self._c)
+        return self._lib.dcp_gpu_last_scan_launches(self._c)
 
     @property
     def last_scan_redo_pairs(self):
         """Pairs of the last query-lane scan that the row-sweep kernel re-scored (synchronises)."""
         n = C.c_uint(0)
-        self._check(lib.dcp_gpu_last_scan_redo_pairs(self._c, C.byref(n)))
+        self._check(self._lib.dcp_gpu_last_scan_redo_pairs(self._c, C.byref(n)))
         return n.value
 
     @property
     def cells(self):
-        return lib.dcp_gpu_scan_cells(self._c)
+        return self._lib.dcp_gpu_scan_cells(self._c)
 
     @property
     def algorithmic_bytes(self):
-        return lib.dcp_gpu_scan_algorithmic_bytes(self._c)
+        return self._lib.dcp_gpu_scan_algorithmic_bytes(self._c)
 
     def scores(self):
         """(null[nseqs, nprofiles], alt[nseqs, nprofiles]) of the last scan."""
         nl = np.zeros((self.nseqs, self.nprofiles), np.float32)
         al = np.zeros_like(nl)
-        self._check(lib.dcp_gpu_fetch_scores(self._c, nl.ctypes.data, al.ctypes.data))
+        self._check(self._lib.dcp_gpu_fetch_scores(self._c, nl.ctypes.data, al.ctypes.data))
         return nl, al
 
     def trace_paths(self, hits, multi_hits=True, hmmer3_compat=False, null_model=False):
@@ -595,7 +606,7 @@ class Scanner:
         cap = int(sum(2 * int(self._seq_lens[q]) + 2 * self._profiles[p].core_size + 16
                       for q, p in zip(h["seq_idx"], h["profile_idx"]))) if n else 0
         steps = np.zeros(max(cap, 1), STEP_DTYPE)
-        self._check(lib.dcp_gpu_trace_paths(self._c, h.ctypes.data, n, int(multi_hits), int(hmmer3_compat),
+        self._check(self._lib.dcp_gpu_trace_paths(self._c, h.ctypes.data, n, int(multi_hits), int(hmmer3_compat),
                                             int(null_model), steps.ctypes.data, cap, off.ctypes.data,
                                             alt.ctypes.data))
         return [steps[off[i]:off[i + 1]].copy() for i in range(n)], alt
@@ -603,7 +614,7 @@ class Scanner:
     def hits(self, cap=1 << 20):
         buf = np.zeros(cap, HIT_DTYPE)
         n = C.c_uint(0)
-        rc = lib.dcp_gpu_fetch_hits(self._c, buf.ctypes.data, cap, C.byref(n))
+        rc = self._lib.dcp_gpu_fetch_hits(self._c, buf.ctypes.data, cap, C.byref(n))
         if rc == RC_ENOMEM and n.value > cap:
             return self.hits(n.value)
         self._check(rc)

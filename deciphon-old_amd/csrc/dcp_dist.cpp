@@ -13,6 +13,8 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -90,7 +92,7 @@ struct dcp_dist
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, device = 0;
     hipStream_t stream = nullptr;
-    // device staging: {count, profile_offset} of every rank; all ranks' records back to back
+    // device staging: {records held, profile_offset, records found} of every rank; all ranks' records back to back
     uint32_t *d_meta_mine = nullptr, *d_meta_all = nullptr;
     dcp_hit *d_recv = nullptr;
     size_t recv_cap = 0;
@@ -154,8 +156,8 @@ dcp_dist *dcp_dist_init(unsigned char const id[DCP_DIST_ID_BYTES], int rank, int
     std::memcpy(u.internal, id, DCP_DIST_ID_BYTES);
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void **)&d->d_meta_mine, 2 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&d->d_meta_all, 2 * sizeof(uint32_t) * (size_t)nranks) == hipSuccess;
+              hipMalloc((void **)&d->d_meta_mine, DCP_DIST_META_WORDS * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&d->d_meta_all, DCP_DIST_META_WORDS * sizeof(uint32_t) * (size_t)nranks) == hipSuccess;
     if (ok)
     {
         ncclResult_t r = rccl().CommInitRank(&d->comm, nranks, u, rank);
@@ -174,42 +176,63 @@ dcp_dist *dcp_dist_init(unsigned char const id[DCP_DIST_ID_BYTES], int rank, int
 }
 
 // Rendezvous through a file for launchers without any other channel (a plain C program started once
-// per GPU): rank 0 writes the id to `path` (atomically, via rename), the others wait for it.
+// per GPU): rank 0 writes {magic, nranks, id} to `path` (atomically, via rename), the others wait for it.
+// The path must be FRESH for every run: rank 0 removes whatever lies there before it creates its id, and
+// the other ranks refuse a file that is not this layout, names another rank count, or was written more
+// than kStaleSeconds before they arrived -- a left-over id would give ranks different communicators and
+// ncclCommInitRank would block without a timeout.
+namespace
+{
+constexpr uint32_t kIdFileMagic = 0xDC9D1573u;
+constexpr double kStaleSeconds = 120.0;
+struct IdFile
+{
+    uint32_t magic, nranks;
+    unsigned char id[DCP_DIST_ID_BYTES];
+};
+} // namespace
+
 dcp_dist *dcp_dist_init_from_file(char const *path, int rank, int nranks, int device, double timeout_s)
 {
-    if (!path) return nullptr;
-    unsigned char id[DCP_DIST_ID_BYTES];
+    if (!path || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
+    IdFile f;
     if (rank == 0)
     {
-        if (dcp_dist_unique_id(id)) return nullptr;
+        (void)::unlink(path); // a previous run's id must not be picked up by a fast peer
+        if (dcp_dist_unique_id(f.id)) return nullptr;
+        f.magic = kIdFileMagic, f.nranks = (uint32_t)nranks;
         std::string tmp = std::string(path) + ".tmp";
         FILE *fp = std::fopen(tmp.c_str(), "wb");
         if (!fp) return nullptr;
-        bool ok = std::fwrite(id, 1, sizeof id, fp) == sizeof id;
+        bool ok = std::fwrite(&f, 1, sizeof f, fp) == sizeof f;
         ok = std::fclose(fp) == 0 && ok;
         if (!ok || std::rename(tmp.c_str(), path) != 0) return nullptr;
     }
     else
     {
         auto const t0 = std::chrono::steady_clock::now();
+        time_t const arrived = ::time(nullptr);
         for (;;)
         {
             FILE *fp = std::fopen(path, "rb");
             if (fp)
             {
-                size_t n = std::fread(id, 1, sizeof id, fp);
+                size_t n = std::fread(&f, 1, sizeof f, fp);
+                struct stat sb;
+                bool const fresh = ::fstat(fileno(fp), &sb) == 0 && difftime(arrived, sb.st_mtime) <= kStaleSeconds;
                 std::fclose(fp);
-                if (n == sizeof id) break;
+                if (n == sizeof f && f.magic == kIdFileMagic && f.nranks == (uint32_t)nranks && fresh) break;
             }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
             {
-                std::fprintf(stderr, "dcp_dist[%d/%d]: no id in %s after %.0f s\n", rank, nranks, path, timeout_s);
+                std::fprintf(stderr, "dcp_dist[%d/%d]: no fresh id for %d ranks in %s after %.0f s\n", rank, nranks, nranks, path,
+                             timeout_s);
                 return nullptr;
             }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
-    return dcp_dist_init(id, rank, nranks, device);
+    return dcp_dist_init(f.id, rank, nranks, device);
 }
 
 void dcp_dist_free(dcp_dist *d)
@@ -262,7 +285,32 @@ long dcp_dist_merge_hits(unsigned const *counts, unsigned const *profile_offset,
     return (long)total;
 }
 
-// All ranks call this after their scan has been enqueued on `scan_stream` (dcp_gpu_stream(ctx)).
+// The decisions every rank takes from the gathered meta words {held, profile_offset, found} x nranks:
+// counts and offsets per rank, 64-bit displacements, whether ANY rank found more records than it holds
+// (its buffer overflowed: the global list would be truncated, so every rank must report it), and the
+// total.  Pure host code, covered on CPU.  DCP_EINVAL if the total does not fit the 32-bit record count
+// of the interface or a rank claims to hold more than it found.
+int dcp_dist_gather_plan(uint32_t const *meta, int nranks, unsigned *counts, unsigned *profile_offset,
+                         uint64_t *displ, int *any_overflow, uint64_t *total)
+{
+    if (!meta || nranks < 1 || !counts || !profile_offset || !displ || !any_overflow || !total) return DCP_EINVAL;
+    *any_overflow = 0;
+    displ[0] = 0;
+    for (int r = 0; r < nranks; ++r)
+    {
+        uint32_t const held = meta[(size_t)DCP_DIST_META_WORDS * r], found = meta[(size_t)DCP_DIST_META_WORDS * r + 2];
+        if (held > found) return DCP_EINVAL;
+        if (found > held) *any_overflow = 1;
+        counts[r] = held;
+        profile_offset[r] = meta[(size_t)DCP_DIST_META_WORDS * r + 1];
+        displ[r + 1] = displ[r] + held;
+    }
+    *total = displ[nranks];
+    return *total > 0xffffffffull ? DCP_EINVAL : DCP_OK;
+}
+
+// All ranks call this after their scan is COMPLETE (dcp_gpu_sync: a query-lane scan finishes its redo
+// pairs there -- dcp_dist_gather_scan_hits does that itself).
 // hits_dev / nhits_dev: the device hit buffer and counter the scan wrote (dcp_gpu_set_hit_buffer).
 // root >= 0: only that rank receives (gather-v); root < 0: every rank receives (all-gather-v).
 // On a receiving rank *out is a malloc'ed array of *nout records (caller frees), global profile
@@ -279,26 +327,26 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
     // the scan must have finished writing its records and counter
     if (scan_stream) DIST_HIP(d, hipStreamSynchronize((hipStream_t)scan_stream));
 
-    // 1. {count, profile_offset} of every rank: one all-gather of 2 words
-    uint32_t mine[2] = {0, profile_offset};
-    DIST_HIP(d, hipMemcpy(&mine[0], nhits_dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // 1. {records held, profile_offset, records found} of every rank: one all-gather of 3 words
+    uint32_t mine[DCP_DIST_META_WORDS] = {0, profile_offset, 0};
+    DIST_HIP(d, hipMemcpy(&mine[2], nhits_dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
     // A rank whose buffer overflowed still takes part in both exchanges (leaving here would hang its
-    // peers inside the collective): it contributes the records it holds and reports the overflow at the end.
-    bool const overflow = mine[0] > cap;
-    if (overflow) mine[0] = cap;
+    // peers inside the collective): it contributes the records it holds, and the third word tells EVERY
+    // rank that the global list is incomplete -- all of them return DCP_ENOMEM.
+    mine[0] = mine[2] > cap ? cap : mine[2];
     DIST_HIP(d, hipMemcpyAsync(d->d_meta_mine, mine, sizeof mine, hipMemcpyHostToDevice, d->stream));
-    DIST_NCCL(d, rccl().AllGather(d->d_meta_mine, d->d_meta_all, 2, ncclUint32, d->comm, d->stream));
-    std::vector<uint32_t> meta((size_t)2 * R);
+    DIST_NCCL(d, rccl().AllGather(d->d_meta_mine, d->d_meta_all, DCP_DIST_META_WORDS, ncclUint32, d->comm, d->stream));
+    std::vector<uint32_t> meta((size_t)DCP_DIST_META_WORDS * R);
     DIST_HIP(d, hipMemcpyAsync(meta.data(), d->d_meta_all, meta.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     DIST_HIP(d, hipStreamSynchronize(d->stream));
-    std::vector<unsigned> counts((size_t)R), offs((size_t)R), displ((size_t)R + 1, 0);
-    for (int r = 0; r < R; ++r)
-    {
-        counts[(size_t)r] = meta[(size_t)2 * r];
-        offs[(size_t)r] = meta[(size_t)2 * r + 1];
-        displ[(size_t)r + 1] = displ[(size_t)r] + counts[(size_t)r];
-    }
-    uint64_t const total = displ[(size_t)R];
+    std::vector<unsigned> counts((size_t)R), offs((size_t)R);
+    std::vector<uint64_t> displ((size_t)R + 1, 0);
+    int any_overflow = 0;
+    uint64_t total = 0;
+    // every rank sees the same meta words, so every rank takes the same branch here: nobody is left
+    // waiting in the record exchange below
+    if (dcp_dist_gather_plan(meta.data(), R, counts.data(), offs.data(), displ.data(), &any_overflow, &total))
+        return d->fail(DCP_EINVAL, "hit gather", "more than 2^32 - 1 records in all, or inconsistent counts");
     *nout = (unsigned)total;
     bool const receiver = root < 0 || root == d->rank;
 
@@ -334,10 +382,11 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
         if (gr != ncclSuccess) return d->fail(DCP_EFAIL, "ncclSend/ncclRecv", rccl().GetErrorString(gr));
         if (ge != ncclSuccess) return d->fail(DCP_EFAIL, "ncclGroupEnd", rccl().GetErrorString(ge));
     }
+    char const *const ovf = "a rank found more hits than its device buffer holds: the gathered list is incomplete";
     if (!receiver)
     {
         DIST_HIP(d, hipStreamSynchronize(d->stream));
-        return overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", "more hits than the device buffer holds") : DCP_OK;
+        return any_overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", ovf) : DCP_OK;
     }
     // 3. to the host; global indices; (seq, profile) order
     std::vector<dcp_hit> raw((size_t)total);
@@ -352,7 +401,35 @@ int dcp_dist_gather_hits(dcp_dist *d, void const *hits_dev, void const *nhits_de
         return d->fail(DCP_EFAIL, "merge", "inconsistent counts");
     }
     *out = res;
-    return overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", "more hits than the device buffer holds") : DCP_OK;
+    return any_overflow ? d->fail(DCP_ENOMEM, "hit buffer overflow", ovf) : DCP_OK;
+}
+
+// The gather for a scan context: completes the scan first (dcp_gpu_sync -- after a query-lane scan that
+// is where the redo lists are checked and an overflowed scan is repeated with the row sweep, so the hit
+// list is final), then gathers the buffer the scan wrote.  This is the form hosts should call.
+int dcp_dist_gather_scan_hits(dcp_dist *d, dcp_gpu_ctx *ctx, unsigned profile_offset, int root,
+                              struct dcp_hit **out, unsigned *nout)
+{
+    if (!d || !ctx || !out || !nout) return DCP_EINVAL;
+    *out = nullptr;
+    *nout = 0;
+    // A rank whose scan failed must still enter the collective, or its peers would wait for it forever:
+    // it takes part with an empty list and reports its own error afterwards.
+    int const src = dcp_gpu_sync(ctx);
+    void *hits_dev = nullptr, *nhits_dev = nullptr;
+    unsigned cap = 0;
+    int const brc = src ? src : dcp_gpu_hit_buffer(ctx, &hits_dev, &nhits_dev, &cap);
+    if (brc)
+    {
+        DIST_HIP(d, hipSetDevice(d->device));
+        uint32_t *zero = d->d_meta_mine + 2; // a device word holding 0 for the duration of the call
+        DIST_HIP(d, hipMemsetAsync(zero, 0, sizeof(uint32_t), d->stream));
+        DIST_HIP(d, hipStreamSynchronize(d->stream));
+        int const grc = dcp_dist_gather_hits(d, zero, zero, 0, profile_offset, root, nullptr, out, nout);
+        (void)grc;
+        return d->fail(brc, "scan", dcp_gpu_last_error(ctx));
+    }
+    return dcp_dist_gather_hits(d, hits_dev, nhits_dev, cap, profile_offset, root, nullptr, out, nout);
 }
 
 void dcp_dist_free_hits(struct dcp_hit *hits) { std::free(hits); }

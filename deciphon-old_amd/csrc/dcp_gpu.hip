@@ -121,7 +121,7 @@ struct dcp_gpu_ctx
     int last_kernel = 0; // 1 row sweep, 2 query lane
     unsigned qorder_nt = 0;         // block size the cached query order / transposed words were built for
     int last_kernel_variant = 0; // as dcp_scan_params.kernel names it: 1, 2 or 3 (two-stage query lane)
-    unsigned redo_cap_limit = 1u << 26; // dcp_gpu_test_set_redo_cap
+    unsigned redo_cap_limit = 1u << 26; // only the -DDCP_TEST_HOOKS build can change it
     float last_ql_ms = 0;
 
     // resident sequences
@@ -1142,12 +1142,14 @@ static int finish_scan(dcp_gpu_ctx *c)
     return DCP_OK;
 }
 
+#ifdef DCP_TEST_HOOKS
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)
 {
     if (!c) return DCP_EINVAL;
     c->redo_cap_limit = cap ? cap : 1u << 26;
     return DCP_OK;
 }
+#endif
 
 int dcp_gpu_sync(dcp_gpu_ctx *c)
 {

@@ -20,26 +20,39 @@ from . import HIT_DTYPE, DcpError, RC_EFAIL, lib, partition_by_cells
 HIT_WORDS = 4  # struct dcp_hit = 4 x 32-bit words
 ID_BYTES = 128
 
-lib.dcp_dist_unique_id.restype = C.c_int
-lib.dcp_dist_unique_id.argtypes = [C.c_void_p]
-lib.dcp_dist_init.restype = C.c_void_p
-lib.dcp_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-lib.dcp_dist_init_from_file.restype = C.c_void_p
-lib.dcp_dist_init_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double]
-lib.dcp_dist_free.restype = None
-lib.dcp_dist_free.argtypes = [C.c_void_p]
-lib.dcp_dist_last_error.restype = C.c_char_p
-lib.dcp_dist_last_error.argtypes = [C.c_void_p]
-lib.dcp_dist_shard.restype = None
-lib.dcp_dist_shard.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
-lib.dcp_dist_gather_hits.restype = C.c_int
-lib.dcp_dist_gather_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_void_p,
-                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint)]
-lib.dcp_dist_free_hits.restype = None
-lib.dcp_dist_free_hits.argtypes = [C.c_void_p]
-lib.dcp_dist_merge_hits.restype = C.c_long
-lib.dcp_dist_merge_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint]
+def bind(lib):
+    """ctypes prototypes of the dcp_dist_* entry points on a loaded library (the shipped one below; the tests' own
+    -DDCP_TEST_HOOKS build through CDist.create(..., lib=...))."""
+    lib.dcp_dist_unique_id.restype = C.c_int
+    lib.dcp_dist_unique_id.argtypes = [C.c_void_p]
+    lib.dcp_dist_init.restype = C.c_void_p
+    lib.dcp_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.dcp_dist_init_from_file.restype = C.c_void_p
+    lib.dcp_dist_init_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.dcp_dist_free.restype = None
+    lib.dcp_dist_free.argtypes = [C.c_void_p]
+    lib.dcp_dist_last_error.restype = C.c_char_p
+    lib.dcp_dist_last_error.argtypes = [C.c_void_p]
+    lib.dcp_dist_shard.restype = None
+    lib.dcp_dist_shard.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    lib.dcp_dist_gather_hits.restype = C.c_int
+    lib.dcp_dist_gather_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_void_p,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint)]
+    lib.dcp_dist_gather_scan_hits.restype = C.c_int
+    lib.dcp_dist_gather_scan_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_uint)]
+    lib.dcp_dist_gather_plan.restype = C.c_int
+    lib.dcp_dist_gather_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_uint64)]
+    lib.dcp_dist_free_hits.restype = None
+    lib.dcp_dist_free_hits.argtypes = [C.c_void_p]
+    lib.dcp_dist_merge_hits.restype = C.c_long
+    lib.dcp_dist_merge_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint]
 
+    return lib
+
+
+bind(lib)
 
 def shard_range(core_sizes, world_size, rank):
     """[begin, end) of rank's contiguous profile shard (dcp_dist_shard)."""
@@ -73,11 +86,28 @@ def merge_hits(counts, profile_offsets, records):
     return out[:total]
 
 
+META_WORDS = 3  # DCP_DIST_META_WORDS: records held, profile offset, records found
+
+
+def gather_plan(meta):
+    """dcp_dist_gather_plan: meta [nranks, 3] uint32 -> (counts, offsets, displ[nranks+1] uint64, any_overflow, total).
+    Raises DcpError(EINVAL) when the total exceeds 2^32 - 1 or a rank holds more than it found."""
+    m = np.ascontiguousarray(meta, np.uint32).reshape(-1, META_WORDS)
+    n = len(m)
+    counts, offs, displ = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n + 1, np.uint64)
+    ovf, total = C.c_int(0), C.c_uint64(0)
+    rc = lib.dcp_dist_gather_plan(m.ctypes.data, n, counts.ctypes.data, offs.ctypes.data, displ.ctypes.data,
+                                  C.byref(ovf), C.byref(total))
+    if rc:
+        raise DcpError(rc, "dcp_dist_gather_plan")
+    return counts, offs, displ, bool(ovf.value), int(total.value)
+
+
 class CDist:
     """The C host's RCCL communicator (dcp_dist_*): one per process / GPU."""
 
-    def __init__(self, handle, rank, world):
-        self._h, self.rank, self.world = handle, rank, world
+    def __init__(self, handle, rank, world, lib_=None):
+        self._h, self.rank, self.world, self._lib = handle, rank, world, lib_ or lib
 
     @staticmethod
     def unique_id():
@@ -88,34 +118,46 @@ class CDist:
         return bytes(buf)
 
     @classmethod
-    def create(cls, id_bytes, rank, world, device):
+    def create(cls, id_bytes, rank, world, device, lib_=None):
+        """lib_: another build of the library (tests: load_testhooks()) whose contexts this communicator serves."""
+        use = bind(lib_) if lib_ is not None else lib
         buf = (C.c_ubyte * ID_BYTES).from_buffer_copy(id_bytes)
-        h = lib.dcp_dist_init(buf, rank, world, device)
+        h = use.dcp_dist_init(buf, rank, world, device)
         if not h:
             raise DcpError(RC_EFAIL, "ncclCommInitRank failed")
-        return cls(h, rank, world)
+        return cls(h, rank, world, use)
+
+    def gather_scan_hits(self, scanner, profile_offset, root=-1):
+        """dcp_dist_gather_scan_hits: completes `scanner`'s scan (dcp_gpu_sync: redo lists checked), then
+        gathers the buffer it wrote.  Returns (records or None, global total)."""
+        out, n = C.c_void_p(), C.c_uint(0)
+        rc = self._lib.dcp_dist_gather_scan_hits(self._h, scanner._c, profile_offset, root, C.byref(out), C.byref(n))
+        return self._take(rc, out, n)
 
     def gather_hits(self, hits_dev_ptr, count_dev_ptr, cap, profile_offset, scan_stream, root=-1):
-        """All ranks call it after their scan; returns (records or None, global total)."""
+        """All ranks call it after their scan is complete (Scanner.sync); returns (records or None, global total)."""
         out, n = C.c_void_p(), C.c_uint(0)
-        rc = lib.dcp_dist_gather_hits(self._h, hits_dev_ptr, count_dev_ptr, cap, profile_offset, root, scan_stream,
+        rc = self._lib.dcp_dist_gather_hits(self._h, hits_dev_ptr, count_dev_ptr, cap, profile_offset, root, scan_stream,
                                       C.byref(out), C.byref(n))
+        return self._take(rc, out, n)
+
+    def _take(self, rc, out, n):
         if rc:
             if out.value:  # an overflow is reported after the exchange, with the (truncated) list allocated
-                lib.dcp_dist_free_hits(out)
-            raise DcpError(rc, lib.dcp_dist_last_error(self._h).decode())
+                self._lib.dcp_dist_free_hits(out)
+            raise DcpError(rc, self._lib.dcp_dist_last_error(self._h).decode())
         if not out.value:
             return None, n.value
         try:
             arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(max(n.value, 1) * HIT_WORDS,))
             return arr[:n.value * HIT_WORDS].copy().view(HIT_DTYPE), n.value
         finally:
-            lib.dcp_dist_free_hits(out)
+            self._lib.dcp_dist_free_hits(out)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib.dcp_dist_free(h)
+            self._lib.dcp_dist_free(h)
 
     __del__ = close
 
@@ -138,10 +180,14 @@ def gather_hits(hit_words, hit_count, profile_offset, slab=4096, group=None):
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     metas = torch.stack(metas).cpu().numpy().astype(np.int64)
-    ns, offs = metas[:, 0], metas[:, 1]
     cap = hit_words.shape[0]
-    if ns.max() > cap:
-        raise RuntimeError(f"hit buffer overflow: {ns.max()} > {cap}")
+    # the same decision as the C path (dcp_dist_gather_plan): every rank learns of any rank's overflow
+    found = metas[:, 0]
+    held = np.minimum(found, cap)  # all ranks use the same capacity in this transport
+    ns, offs, _, overflow, _ = gather_plan(np.stack([held, metas[:, 1], found], axis=1))
+    ns, offs = ns.astype(np.int64), offs.astype(np.int64)
+    if overflow:
+        raise RuntimeError(f"hit buffer overflow on some rank: found {found.max()} > capacity {cap}")
     rows = max(1, min(cap, max(slab, int(ns.max()))))
     mine = hit_words[:rows].contiguous()
     slabs = [torch.empty_like(mine) for _ in range(world)]

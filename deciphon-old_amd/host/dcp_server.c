@@ -328,6 +328,8 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
         if (seqs[q].size == 0) return fail(RC_EINVAL, "sequence cannot be empty");
         total += seqs[q].size;
     }
+    /* the batch's offsets are 32-bit (dcp_gpu_seqs_upload): a batch of 4 Gi symbols or more would wrap them */
+    if (total > UINT32_MAX) return fail(RC_EINVAL, "sequence batch exceeds 2^32 - 1 symbols: scan it in smaller batches");
     /* encode once per batch (imm_task_setup does it per pair: scan_thread.c:51-55); the caller's
      * buffers may be overwritten by its next fetch (scan.c:227-229), nothing here keeps them */
     uint8_t *ids = malloc(total);

@@ -297,10 +297,13 @@ int dcp_gpu_set_hit_buffer(dcp_gpu_ctx *, void *hits_dev, unsigned cap,
  * caller's from dcp_gpu_set_hit_buffer) -- what a C host hands to dcp_dist_gather_hits without touching
  * the HIP API itself.  Call dcp_gpu_sync first: a query-lane scan completes its redo pairs there. */
 int dcp_gpu_hit_buffer(dcp_gpu_ctx *, void **hits_dev, void **nhits_dev, unsigned *cap);
-/* TEST-ONLY: shrink the per-size-class capacity of the redo lists (default 2^26 pairs; 0 restores
- * it) so a test can reach the overflow path.  Results are unaffected: an overflowed scan is
- * repeated with the row-sweep kernel. */
+#ifdef DCP_TEST_HOOKS
+/* NOT in the shipped library: exists only in libdcp_hip_testhooks.so (the same sources compiled with
+ * -DDCP_TEST_HOOKS, loaded by the tests alone).  Shrinks the per-size-class capacity of the redo lists
+ * (default 2^26 pairs; 0 restores it) so a test can reach the overflow path.  Results are unaffected:
+ * an overflowed scan is repeated with the row-sweep kernel. */
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *, unsigned cap);
+#endif
 /* Wait for the stream (and, after a query-lane scan, check its redo lists:
  * see dcp_gpu_last_scan_redo_pairs). */
 int dcp_gpu_sync(dcp_gpu_ctx *);
@@ -395,11 +398,15 @@ char const *dcp_prod_header(void);
  * is the gather of the 16-byte hit records.  librccl.so is loaded on first use. */
 typedef struct dcp_dist dcp_dist;
 enum { DCP_DIST_ID_BYTES = 128 }; /* NCCL_UNIQUE_ID_BYTES */
+enum { DCP_DIST_META_WORDS = 3 }; /* per rank in the meta all-gather: records held, profile offset, records found */
 /* Rank 0 creates the communicator id (ncclGetUniqueId) and hands it to the other ranks through
  * whatever channel the launcher has (bench.py: torch.distributed; a C launcher: the file variant). */
 int dcp_dist_unique_id(unsigned char id[DCP_DIST_ID_BYTES]);
 dcp_dist *dcp_dist_init(unsigned char const id[DCP_DIST_ID_BYTES], int rank, int nranks, int device);
-/* Rendezvous through a file: rank 0 writes the id to `path`, the others wait up to timeout_s for it. */
+/* Rendezvous through a file: rank 0 writes the id to `path`, the others wait up to timeout_s for it.
+ * `path` must be FRESH for every run (e.g. carry the launcher's pid): rank 0 removes what lies there
+ * before creating its id, and the other ranks refuse a file of another layout or rank count or one written
+ * more than 120 s before they arrived -- ranks with different ids would block in ncclCommInitRank. */
 dcp_dist *dcp_dist_init_from_file(char const *path, int rank, int nranks, int device, double timeout_s);
 void dcp_dist_free(dcp_dist *);
 int dcp_dist_rank(dcp_dist const *);
@@ -408,18 +415,31 @@ char const *dcp_dist_last_error(dcp_dist const *);
 /* [begin, end) of rank's shard: dcp_partition_by_cells over nranks. */
 void dcp_dist_shard(unsigned const *core_sizes, unsigned nprofiles, int nranks, int rank, unsigned *begin,
                     unsigned *end);
-/* Gather the hit records of every rank's last scan.  hits_dev / nhits_dev: the device buffer and counter
- * the scan wrote (dcp_gpu_set_hit_buffer); profile_offset: first global profile index of this rank's
- * shard (records carry shard-local indices); scan_stream: dcp_gpu_stream(ctx) (synchronised first).
- * Counts + offsets travel in one 2-word all-gather, the records in one grouped ncclSend/ncclRecv
- * (gather-v).  root >= 0: only that rank receives; root < 0: every rank does.  On a receiving rank
- * *out is a malloc'ed array (dcp_dist_free_hits) of *nout records with GLOBAL profile indices,
- * ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total.
- * A rank whose scan found more than `cap` hits still completes both exchanges with the records it holds
- * (its peers are not left waiting) and then returns DCP_ENOMEM -- on a receiving rank with *out set. */
+/* Gather the hit records of every rank's last scan -- the form hosts call: completes the scan of `ctx`
+ * first (dcp_gpu_sync: a query-lane scan finishes its redo pairs there, and a scan whose redo lists
+ * overflowed is repeated with the row sweep, so the list that travels is final), then gathers the buffer
+ * that scan wrote.  profile_offset: first global profile index of this rank's shard (records carry
+ * shard-local indices).  {held, offset, found} of every rank travel in one 3-word all-gather, the records
+ * in one grouped ncclSend/ncclRecv (gather-v).  root >= 0: only that rank receives; root < 0: every rank
+ * does.  On a receiving rank *out is a malloc'ed array (dcp_dist_free_hits) of *nout records with GLOBAL
+ * profile indices, ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total.
+ * If ANY rank's scan found more hits than its buffer holds, every rank still completes both exchanges
+ * with the records there are (nobody is left waiting) and then EVERY rank returns DCP_ENOMEM -- on a
+ * receiving rank with *out set to the incomplete list.  A rank whose scan failed takes part with an
+ * empty list and returns its scan's error.  More than 2^32 - 1 records in all: DCP_EINVAL everywhere. */
+int dcp_dist_gather_scan_hits(dcp_dist *, dcp_gpu_ctx *ctx, unsigned profile_offset, int root,
+                              struct dcp_hit **out, unsigned *nout);
+/* The same for an explicit device buffer (hits_dev / nhits_dev / cap as given to dcp_gpu_set_hit_buffer).
+ * The caller must have completed the scan with dcp_gpu_sync(ctx) -- synchronising the stream alone (what
+ * a non-NULL scan_stream does here) does not check the redo lists of a query-lane scan. */
 int dcp_dist_gather_hits(dcp_dist *, void const *hits_dev, void const *nhits_dev, unsigned cap,
                          unsigned profile_offset, int root, void *scan_stream, struct dcp_hit **out,
                          unsigned *nout);
+/* What every rank derives from the gathered meta words ({held, profile_offset, found} x nranks): counts,
+ * offsets, 64-bit displacements displ[nranks + 1], whether any rank overflowed, the total.  Host only.
+ * DCP_EINVAL when the total exceeds 2^32 - 1 or a rank holds more than it found. */
+int dcp_dist_gather_plan(uint32_t const *meta, int nranks, unsigned *counts, unsigned *profile_offset,
+                         uint64_t *displ, int *any_overflow, uint64_t *total);
 void dcp_dist_free_hits(struct dcp_hit *hits);
 /* The bookkeeping of the gather alone (host, no device, no RCCL): counts[r] records of rank r lie back
  * to back in `records`; out receives them with profile_idx += profile_offset[r], ordered by

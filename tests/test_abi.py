@@ -9,9 +9,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(hooks=False):
     text = open(os.path.join(ROOT, "include", "dcp_gpu.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    hook_blocks = re.findall(r"#ifdef DCP_TEST_HOOKS(.*?)#endif", text, flags=re.S)
+    if hooks:
+        text = "".join(hook_blocks)
+    else:
+        text = re.sub(r"#ifdef DCP_TEST_HOOKS.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dcp_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -22,6 +27,21 @@ def test_header_symbols_exported(dcp):
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(dcp.ABI_SYMBOLS) == syms
+
+
+def test_test_hooks_are_not_in_the_shipped_library(dcp):
+    """Knobs on the result path (dcp_gpu_test_set_redo_cap) exist only in the tests' own
+    -DDCP_TEST_HOOKS build, never in libdcp_hip.so or the host library."""
+    hooks = declared_symbols(hooks=True)
+    assert hooks == ["dcp_gpu_test_set_redo_cap"]
+    shipped = C.CDLL(dcp.LIB_PATH)
+    assert not [h for h in hooks if hasattr(shipped, h)]
+    host = os.path.join(os.path.dirname(dcp.LIB_PATH), "libdeciphon_host.so")
+    if os.path.exists(host):
+        assert not [h for h in hooks if hasattr(C.CDLL(host), h)]
+    test_build = C.CDLL(dcp.TESTHOOKS_LIB_PATH)
+    assert all(hasattr(test_build, h) for h in hooks)
+    assert all(hasattr(test_build, s) for s in declared_symbols())  # otherwise the same library
 
 
 def test_no_oracle_in_product():

@@ -77,6 +77,14 @@ def _worker(rank, world, port, tmpdir):
             raise AssertionError("overflow not detected")
         except RuntimeError:
             pass
+        # ... on EVERY rank, also when only one rank's buffer overflowed (the peers of an
+        # overflowed rank must not return a silently truncated list)
+        try:
+            ddist.gather_hits(torch.zeros((4, 4), dtype=torch.int32),
+                              torch.tensor([9 if rank == 1 else 2], dtype=torch.int32), b)
+            raise AssertionError(f"rank {rank}: a peer's overflow went unnoticed")
+        except RuntimeError:
+            pass
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -87,6 +95,53 @@ def test_shard_and_gather_world2(tmp_path):
     port = 29500 + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_gather_plan_bookkeeping(dcp):
+    """dcp_dist_gather_plan: what every rank derives from the {held, offset, found} words of the meta
+    all-gather -- counts, offsets, 64-bit displacements, and ONE overflow verdict for all ranks."""
+    from deciphon_old_amd import dist as ddist
+
+    counts, offs, displ, ovf, total = ddist.gather_plan([[3, 0, 3], [0, 70, 0], [5, 90, 5]])
+    assert list(counts) == [3, 0, 5] and list(offs) == [0, 70, 90] and list(displ) == [0, 3, 3, 8]
+    assert not ovf and total == 8
+    # rank 1 found 9 records but its buffer holds 4: everybody learns it
+    counts, _, displ, ovf, total = ddist.gather_plan([[2, 0, 2], [4, 50, 9]])
+    assert ovf and list(counts) == [2, 4] and total == 6 and list(displ) == [0, 2, 6]
+    # displacements are 64-bit: three ranks with 2^31 records each do not wrap, but the total does not fit the interface
+    big = 1 << 31
+    with pytest.raises(dcp.DcpError):
+        ddist.gather_plan([[big, 0, big], [big, 1, big], [big, 2, big]])
+    counts, _, displ, ovf, total = ddist.gather_plan([[big, 0, big], [big - 1, 1, big - 1]])
+    assert total == 2 * big - 1 and int(displ[2]) == 2 * big - 1 and not ovf
+    # a rank cannot hold more than it found
+    with pytest.raises(dcp.DcpError):
+        ddist.gather_plan([[5, 0, 4]])
+
+
+def test_id_file_must_be_fresh(dcp, tmp_path):
+    """dcp_dist_init_from_file, rank > 0: a left-over file (old layout, another rank count, or older than
+    the staleness bound) is refused -- the call times out instead of joining a communicator of its own
+    (ADVICE r2).  Fails before anything touches a device, so it runs on CPU."""
+    import ctypes as C
+    import struct
+    import time
+    from deciphon_old_amd import dist as ddist
+
+    lib = dcp.lib
+    path = tmp_path / "id"
+    path.write_bytes(bytes(128))  # round 2's layout: a bare 128-byte id
+    t0 = time.time()
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
+    assert time.time() - t0 < 5
+    path.write_bytes(struct.pack("<II", 0xDC9D1573, 4) + bytes(128))  # a run with 4 ranks, we are one of 2
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
+    path.write_bytes(struct.pack("<II", 0xDC9D1573, 2) + bytes(128))  # right layout, written long ago
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
+    assert not lib.dcp_dist_init_from_file(None, 0, 1, 0, 0.1)
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 2, 2, 0, 0.1)  # rank out of range
 
 
 def _gpu_worker(rank, world, port, tmpdir):
@@ -179,7 +234,57 @@ def test_c_rccl_gather_one_rank(dcp):
         # a shard that does not start at profile 0: indices come back global
         got, _ = comm.gather_hits(hits_dev.data_ptr(), count_dev.data_ptr(), cap, 1000, sc.stream)
         assert np.array_equal(got["profile_idx"], want["profile_idx"] + 1000)
+        # the form hosts call: the gather completes the scan itself (dcp_gpu_sync) and takes the context's buffer
+        sc.scan(True, False, 10.0, sync=False)
+        got, total = comm.gather_scan_hits(sc, 0)
+        assert total == len(want) and np.array_equal(got, want)
+        # a buffer too small for the scan's hits: DCP_ENOMEM, not a short list taken for the whole
+        sc.set_hit_buffer(hits_dev.data_ptr(), 1, count_dev.data_ptr())
+        sc.scan(True, False, 10.0, sync=False)
+        with pytest.raises(dcp.DcpError) as ei:
+            comm.gather_scan_hits(sc, 0)
+        assert ei.value.rc == dcp.RC_ENOMEM
         sc.set_hit_buffer(None, 0, None)
+        # without a caller buffer the context's own one is gathered
+        sc.scan(True, False, 10.0, sync=False)
+        got, _ = comm.gather_scan_hits(sc, 0)
+        assert np.array_equal(got, want)
+    finally:
+        comm.close()
+        sc.close()
+
+
+@pytest.mark.gpu
+def test_gather_after_redo_list_overflow(dcp):
+    """a query-lane scan whose redo lists overflowed loses pairs until dcp_gpu_sync repeats it
+    with the row sweep.  dcp_dist_gather_scan_hits runs that completion before it reads the hit buffer,
+    so the gathered list is the full one (context of the tests' -DDCP_TEST_HOOKS build: that is where the
+    redo capacity can be shrunk to one pair per size class)."""
+    from deciphon_old_amd import dist as ddist
+    import test_gpu_parity as tp
+    from oracle_py import Oracle
+
+    rng = np.random.default_rng(33)
+    M = 60
+    prm = tp.pfam_like_params(rng, M)
+    cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+    oprof = Oracle(32).new(*prm, dcp.ENTRY_DIST_OCCUPANCY, 0.01)
+    two = lambda: np.concatenate([tp.planted_query(rng, oprof, M), tp.planted_query(rng, oprof, M)])
+    seqs = [two(), two(), two()] + tp.rand_seqs(rng, 5, 100, 300)
+    hooks = dcp.load_testhooks()
+    sc = dcp.Scanner(0, lib=hooks)
+    comm = ddist.CDist.create(ddist.CDist.unique_id(), 0, 1, 0, lib_=hooks)
+    try:
+        sc.upload_db([dcp.ProteinProfile.from_params(*prm, cfg)])
+        sc.upload_seqs(seqs)
+        sc.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+        want = sc.hits()
+        assert [(int(h["seq_idx"]), int(h["profile_idx"])) for h in want][:3] == [(0, 0), (1, 0), (2, 0)]
+        sc.test_set_redo_cap(1)
+        sc.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE, sync=False)  # 3 feedback pairs, room for 1
+        got, total = comm.gather_scan_hits(sc, 0)
+        assert total == len(want) and np.array_equal(got, want)
+        sc.test_set_redo_cap(0)
     finally:
         comm.close()
         sc.close()

@@ -26,6 +26,15 @@ def scanner(dcp):
     s.close()
 
 
+@pytest.fixture(scope="module")
+def hooks_scanner(dcp):
+    """A context of the tests' own -DDCP_TEST_HOOKS build of the library (libdcp_hip_testhooks.so): the
+    shipped library does not export dcp_gpu_test_set_redo_cap."""
+    s = dcp.Scanner(0, lib=dcp.load_testhooks())
+    yield s
+    s.close()
+
+
 @pytest.fixture(params=["rowsweep", "qlane", "qlane2"])
 def kern(request, dcp):
     """Every parity test runs on every kernel: the row sweep (one wavefront group per pair), the
@@ -295,9 +304,10 @@ def test_explicit_special_transitions(dcp, oracle32, scanner, kern):
         scanner.set_xtrans(xt[:3])
 
 
-def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, scanner):
+def test_redo_list_overflow_falls_back_to_row_sweep(dcp, oracle32, hooks_scanner):
     """More feedback pairs than a redo list holds: the scan is repeated by the row-sweep kernel
     and stays bit-exact (the test-only setter shrinks the lists to one pair per size class)."""
+    scanner = hooks_scanner
     rng = np.random.default_rng(33)
     M = 60
     prm = pfam_like_params(rng, M)
