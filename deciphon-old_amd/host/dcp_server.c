@@ -638,6 +638,8 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
 #pragma omp atomic write
                 shared = r; /* scan.c:246-248: a failing partition fails the scan */
             }
+            else if (cfg.progress)
+                cfg.progress((unsigned long)nb * reader->partition_size[i], cfg.progress_arg);
         }
         rc = shared;
     }
@@ -697,7 +699,7 @@ enum rc scan_run_local(char const *db_filename, struct scan_seq const *seqs, uns
 {
     if (!seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
     struct list_source src = {seqs, nseqs, 0};
-    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true, false};
+    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true, false, NULL, NULL};
     enum rc rc = scan_run_source(db_filename, cfg, nthreads, list_next, &src);
     if (rc) return rc;
     char buf[1 << 16];

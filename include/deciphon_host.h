@@ -850,6 +850,12 @@ struct scan_cfg
      * wants (20k profiles: 1.5 s per job).  Device memory stays allocated until scan_resident_release()
      * or a scan of another database. */
     bool keep_resident;
+    /* Batched progress (the reference consumes one unit per (profile, sequence) pair inside thread_run,
+     * src/core/progress.c:69-94, scan.c:97-102): called once per device pass and partition with the number of
+     * pairs that pass completed, possibly from several host threads at once -- the callee serialises
+     * (integration/scan_run_adapter.c turns it into api_increment_job_progress).  NULL = no reporting. */
+    void (*progress)(unsigned long pairs, void *arg);
+    void *progress_arg;
 };
 void scan_resident_release(void);
 enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned num_threads,

@@ -23,6 +23,7 @@
 #ifndef DCP_ORACLE_H
 #define DCP_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef ORC_F64
@@ -214,6 +215,32 @@ long orc_scan_resident(struct orc_profile *const *profiles, unsigned nprofiles,
                        unsigned char const *seqs, uint32_t const *seq_off, unsigned nseqs,
                        int multi_hits, int hmmer3_compat, double lrt_thr, int nthreads,
                        ofloat *out_null, ofloat *out_alt, double *prepare_seconds, double *dp_seconds);
+
+/* ---- file readers (oracle_io.c): the oracle's OWN parsers of the formats either side of the scan path,
+ * so that parity tests compare the HIP path with the oracle reading the same bytes --- */
+/* Swiss-Prot 50.8 background, src/model/protein_h3reader.c:79-103 */
+void orc_swissprot_null(ofloat out[20]);
+/* HMMER3/f ASCII -> profiles (protein_h3reader_next + protein_profile_absorb) */
+struct orc_h3;
+struct orc_h3 *orc_h3_open(char const *path, int entry_dist, ofloat eps);
+/* ORC_OK + *out (caller frees with orc_profile_del), ORC_END, ORC_EFAIL (malformed), ORC_EINVAL (core size) */
+int orc_h3_next(struct orc_h3 *, struct orc_profile **out);
+char const *orc_h3_error(struct orc_h3 const *);
+char const *orc_h3_acc(struct orc_h3 const *);       /* ACC, or NAME without one: of the last profile read */
+char const *orc_h3_consensus(struct orc_h3 const *); /* CONS column of the last profile read */
+void orc_h3_close(struct orc_h3 *);
+/* MessagePack ".dcp" database (src/db/writer.c:95-117, src/model/protein_profile.c:338-400) */
+struct orc_dcp;
+struct orc_dcp *orc_dcp_open(char const *path, char *err, size_t errcap);
+void orc_dcp_close(struct orc_dcp *);
+unsigned orc_dcp_nprofiles(struct orc_dcp const *);
+int orc_dcp_entry_dist(struct orc_dcp const *);
+ofloat orc_dcp_epsilon(struct orc_dcp const *);
+int orc_dcp_profile(struct orc_dcp const *, unsigned i, unsigned *core_size, char *acc, ofloat *trans8,
+                    ofloat *xtrans, struct orc_nuclt_dist *null_d, struct orc_nuclt_dist *insert_d,
+                    struct orc_nuclt_dist *match_d, char *consensus);
+int orc_dcp_score(struct orc_dcp const *, unsigned i, unsigned char const *seq, unsigned L, int multi_hits,
+                  int hmmer3_compat, ofloat *null_loglik, ofloat *alt_loglik);
 
 #ifdef __cplusplus
 }

@@ -22,8 +22,8 @@ R_STATE, S_STATE, N_STATE, B_STATE, E_STATE, J_STATE, C_STATE, T_STATE = (
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle_f32.so")
-    src = os.path.join(ORACLE_DIR, "oracle.c")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.c", "oracle_io.c", "oracle.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
@@ -244,7 +244,110 @@ class Oracle:
             raise ValueError("orc_scan_resident: bad input")
         return hits, on, oa, tp.value, td.value
 
+    # ---- the oracle's own file readers (oracle/oracle_io.c) ------------------------------------------
+    def _bind_io(self):
+        lib, fl = self.lib, self.fl
+        if getattr(lib, "_io_bound", False):
+            return
+        lib.orc_swissprot_null.argtypes = [C.c_void_p]
+        lib.orc_h3_open.restype = C.c_void_p
+        lib.orc_h3_open.argtypes = [C.c_char_p, C.c_int, fl]
+        lib.orc_h3_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        for f in ("orc_h3_error", "orc_h3_acc", "orc_h3_consensus"):
+            getattr(lib, f).restype = C.c_char_p
+            getattr(lib, f).argtypes = [C.c_void_p]
+        lib.orc_h3_close.argtypes = [C.c_void_p]
+        lib.orc_dcp_open.restype = C.c_void_p
+        lib.orc_dcp_open.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.orc_dcp_close.argtypes = [C.c_void_p]
+        lib.orc_dcp_nprofiles.argtypes = [C.c_void_p]
+        lib.orc_dcp_nprofiles.restype = C.c_uint
+        lib.orc_dcp_entry_dist.argtypes = [C.c_void_p]
+        lib.orc_dcp_epsilon.argtypes = [C.c_void_p]
+        lib.orc_dcp_epsilon.restype = fl
+        lib.orc_dcp_profile.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.c_char_p] + [C.c_void_p] * 5 + [C.c_char_p]
+        lib.orc_dcp_score.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_uint, C.c_int, C.c_int, C.POINTER(fl),
+                                      C.POINTER(fl)]
+        lib._io_bound = True
+
+    def swissprot_null(self):
+        self._bind_io()
+        out = np.zeros(20, self.np)
+        self.lib.orc_swissprot_null(out.ctypes.data)
+        return out
+
+    def read_hmmer3(self, path, entry_dist=ENTRY_DIST_OCCUPANCY, epsilon=0.01):
+        """Every profile of a HMMER3 ASCII file through the oracle's own parser:
+        [(Profile, accession-or-name, consensus)].  Raises ValueError(rc, message) on a bad file."""
+        self._bind_io()
+        r = self.lib.orc_h3_open(os.fsencode(str(path)), entry_dist, float(np.float32(epsilon)))
+        if not r:
+            raise ValueError(4, "cannot open")
+        out = []
+        try:
+            while True:
+                h = C.c_void_p()
+                rc = self.lib.orc_h3_next(r, C.byref(h))
+                if rc == 1:
+                    return out
+                if rc:
+                    raise ValueError(rc, self.lib.orc_h3_error(r).decode())
+                out.append((Profile(self, h.value), self.lib.orc_h3_acc(r).decode(), self.lib.orc_h3_consensus(r).decode()))
+        finally:
+            self.lib.orc_h3_close(r)
+
+    def open_dcp(self, path):
+        self._bind_io()
+        return DcpFile(self, path)
+
     def xtrans(self, L, multi_hits=True, hmmer3_compat=False):
         out = np.zeros(13, self.np)
         rc = self.lib.orc_xtrans(L, int(multi_hits), int(hmmer3_compat), out.ctypes.data)
         return rc, out
+
+
+class DcpFile:
+    """A MessagePack .dcp database through the oracle's own reader (oracle/oracle_io.c)."""
+
+    def __init__(self, orc, path):
+        self.orc = orc
+        err = C.create_string_buffer(160)
+        self.h = orc.lib.orc_dcp_open(os.fsencode(str(path)), err, len(err))
+        if not self.h:
+            raise ValueError(err.value.decode())
+        self.nprofiles = orc.lib.orc_dcp_nprofiles(self.h)
+        self.entry_dist = orc.lib.orc_dcp_entry_dist(self.h)
+        self.epsilon = orc.lib.orc_dcp_epsilon(self.h)
+
+    def close(self):
+        h, self.h = self.h, None
+        if h:
+            self.orc.lib.orc_dcp_close(h)
+
+    __del__ = close
+
+    def profile(self, i):
+        """dict(core_size, accession, consensus, trans8 [8,M], xtrans [13], null [129], insert [129], match [M,129])"""
+        o = self.orc
+        m = C.c_uint(0)
+        rc = o.lib.orc_dcp_profile(self.h, i, C.byref(m), None, None, None, None, None, None, None)
+        if rc:
+            raise ValueError(f"profile {i}: rc {rc}")
+        M = m.value
+        acc, cons = C.create_string_buffer(32), C.create_string_buffer(M + 1)
+        t8, xt = np.zeros((8, M), o.np), np.zeros(13, o.np)
+        nd, idd, md = np.zeros(129, o.np), np.zeros(129, o.np), np.zeros((M, 129), o.np)
+        rc = o.lib.orc_dcp_profile(self.h, i, C.byref(m), acc, t8.ctypes.data, xt.ctypes.data, nd.ctypes.data,
+                                   idd.ctypes.data, md.ctypes.data, cons)
+        if rc:
+            raise ValueError(f"profile {i}: rc {rc}")
+        return dict(core_size=M, accession=acc.value.decode(), consensus=cons.value.decode(), trans8=t8, xtrans=xt,
+                    null=nd, insert=idd, match=md)
+
+    def score(self, i, seq: bytes, multi_hits=True, hmmer3_compat=False):
+        o = self.orc
+        nl, al = o.fl(), o.fl()
+        rc = o.lib.orc_dcp_score(self.h, i, seq, len(seq), int(multi_hits), int(hmmer3_compat), C.byref(nl), C.byref(al))
+        if rc:
+            raise ValueError(f"score: rc {rc}")
+        return nl.value, al.value

@@ -100,6 +100,31 @@ def test_db_host_under_sanitizers(dcp, tmp_path):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+STUBS = os.path.join(ROOT, "tests", "c", "stubs")
+
+
+def test_scan_run_adapter_compiles_against_the_scheduler_interfaces(dcp, tmp_path):
+    """integration/scan_run_adapter.c (scan_run(job_id, num_threads), src/server/scan.h:6) builds with -Werror
+    against stub declarations of deciphon/sched/api.h, sched/structs.h, job.h and file.h, and makes the
+    scheduler calls of src/server/scan.c:215-269 and no others."""
+    build_host()
+    assert os.path.exists(build_c_test(tmp_path, "test_scan_run_adapter", extra=["-I", STUBS]))
+    src = open(os.path.join(ROOT, "integration", "scan_run_adapter.c")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    called = set(re.findall(r"\b(api_[a-z_]+)\s*\(", src))
+    assert called == {"api_get_scan_by_job_id", "api_get_db", "api_download_db", "api_scan_num_seqs",
+                      "api_scan_next_seq", "api_increment_job_progress", "api_upload_prods_file", "api_set_job_state"}
+
+
+@pytest.mark.gpu
+def test_scan_run_adapter_on_gpu(tmp_path):
+    build_host()
+    exe = build_c_test(tmp_path, "test_scan_run_adapter", extra=["-I", STUBS])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert "all checks passed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_c_scan_host_on_gpu(tmp_path):
     build_host()
