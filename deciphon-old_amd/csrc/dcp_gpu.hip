@@ -436,7 +436,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         qm.tile_off = tile_floats;
         qm.ttrans_off = (uint32_t)ttrans_floats;
         tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
-        ttrans_floats += (uint64_t)qm.ntiles * KT * 8;
+        ttrans_floats += (uint64_t)qm.ntiles * (KT + 1) * 8;
     }
     if (ttrans_floats > 0xffffffffull) return c->fail(DCP_EINVAL, "DB too large for 32-bit transition offsets");
     HIP_TRY(c, c->d_ql_metas.alloc(nprofiles));
@@ -451,23 +451,15 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             dcp_ql_prof const &qm = c->ql_metas[i];
             float const *src = dcp_profile_trans8(profiles[qm.pidx]);
             unsigned const M = qm.core_size;
-            // per tile 8 arrays of KT floats (TileTrans in dcp_qlane.hip): mi, ii, entry of the tile's own
-            // nodes, then mm, im, dm, md, dd of the edges INTO nodes 1..KT (KT = first node of the next
-            // tile); -inf beyond the profile's last node
-            static int const own[3] = {DCP_T_MI, DCP_T_II, DCP_T_ENTRY};
-            static int const into[5] = {DCP_T_MM, DCP_T_IM, DCP_T_DM, DCP_T_MD, DCP_T_DD};
             for (unsigned t = 0; t < qm.ntiles; ++t)
-            {
-                float *dst = &tt[qm.ttrans_off + (size_t)t * KT * 8];
-                for (unsigned kk = 0; kk < KT; ++kk)
+                for (unsigned kk = 0; kk <= KT; ++kk)
                 {
-                    unsigned const node = t * KT + kk;
-                    for (int a = 0; a < 3; ++a)
-                        if (node < M) dst[(size_t)a * KT + kk] = src[(size_t)own[a] * M + node];
-                    for (int a = 0; a < 5; ++a)
-                        if (node + 1 < M) dst[(size_t)(3 + a) * KT + kk] = src[(size_t)into[a] * M + node + 1];
+                    unsigned node = t * KT + kk;
+                    if (node >= M) break;
+                    float *dst = &tt[qm.ttrans_off + ((size_t)t * (KT + 1) + kk) * 8];
+                    for (int row = 0; row < 8; ++row)
+                        dst[row] = src[(size_t)row * M + node];
                 }
-            }
         }
         HIP_TRY(c, hipMemcpy(c->d_ttrans.p, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice));
     }

@@ -98,7 +98,7 @@ struct dcp_trace_args
 struct dcp_ql_prof
 {
     uint64_t tile_off;   // float offset of the profile's tile images in emis_tiles
-    uint32_t ttrans_off; // float offset of its per-tile transitions [T][8 arrays][KT] (TileTrans)
+    uint32_t ttrans_off; // float offset of its per-tile transitions [T][KT+1][8]
     uint32_t core_size;
     uint32_t ntiles;     // T = ceil(core_size / KT)
     uint32_t pidx;
@@ -112,7 +112,7 @@ struct dcp_qlane_args
     float const *emis_tiles;  // per profile [T][G][1364][4]: the LDS image of each tile
     float const *emis_insert; // [nprof_total][1364]
     float const *emis_null;   // [nprof_total][1364]
-    float const *ttrans;      // per profile [T][8][KT]: mi, ii, entry of the tile's nodes; mm, im, dm, md, dd into nodes 1..KT
+    float const *ttrans;      // per profile [T][KT+1][8] (row KT = edges into the next tile)
     uint32_t const *seq_words;
     uint32_t const *seq_woff;
     uint32_t const *seq_len;

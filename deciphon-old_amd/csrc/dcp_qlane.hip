@@ -91,47 +91,36 @@ struct SweepOut
 };
 
 // The tile's transitions, loaded once per sweep.  They are wave-uniform, so the
-// compiler keeps them in SGPRs.  Re-loading them inside the row loop would cost nothing on the VALU,
-// but SMEM shares the lgkmcnt counter with LDS and returns out of order: every use would force
+// compiler keeps them in SGPRs (free second operand of v_add_f32).  Re-loading
+// them inside the row loop would cost nothing on the VALU, but SMEM shares the
+// lgkmcnt counter with LDS and returns out of order: every use would force
 // s_waitcnt lgkmcnt(0) and drain the LDS gathers in flight.
-//
-// They are kept as PAIRS of consecutive nodes (even-aligned SGPR pairs) because of what the SIMD
-// charges for an add (profiles/r03/valu_issue.txt, measured with the SIMD saturated): v_add_f32 with
-// VGPR operands 2.3 cycles per wavefront, the same add with an SGPR operand 4.15, v_pk_add_f32 -- two
-// adds per lane -- 4.2 with either kind of operand.  A node-row has 8 adds of a transition: as scalar
-// adds with an SGPR operand they cost 33 cycles, as 7 halves of packed adds plus one sequential
-// scalar add (the delete chain) 19.  (v_max_f32 / v_max3_f32 cost 4.2 and have no packed form.)
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef f2 const __attribute__((address_space(4))) cf2;
 template <int G> struct TileTrans
 {
-    // [b]: nodes 2b, 2b+1 of the tile (their own entry and insert edges) ...
-    f2 ent[2 * G], mi[2 * G], ii[2 * G];
-    // ... and the edges OUT of nodes 2b, 2b+1 INTO nodes 2b+1, 2b+2 (node KT = first node of the next tile)
-    f2 mm[2 * G], im[2 * G], dm[2 * G], md[2 * G];
-    float dd[4 * G]; // [k]: D_k -> D_{k+1}; scalar: the delete chain is sequential in k
+    float ent[4 * G], mi[4 * G], ii[4 * G];
+    float mm[4 * G + 1], im[4 * G + 1], dm[4 * G + 1], md[4 * G + 1], dd[4 * G + 1]; // [k]: edges INTO node k
 };
 
-// per-tile transition block in memory (dcp_gpu.hip builds it): 8 arrays of KT floats --
-// mi, ii, ent of nodes 0..KT-1, then mm, im, dm, md, dd of the edges into nodes 1..KT
 template <int G> __device__ __forceinline__ void load_tile_trans(TileTrans<G> &t, cfloat *tt)
 {
-    constexpr int KT = 4 * G, H = 2 * G;
-    cf2 *t2 = (cf2 *)tt;
-#pragma unroll
-    for (int b = 0; b < H; ++b)
-    {
-        t.mi[b] = t2[0 * H + b];
-        t.ii[b] = t2[1 * H + b];
-        t.ent[b] = t2[2 * H + b];
-        t.mm[b] = t2[3 * H + b];
-        t.im[b] = t2[4 * H + b];
-        t.dm[b] = t2[5 * H + b];
-        t.md[b] = t2[6 * H + b];
-    }
+    constexpr int KT = 4 * G;
 #pragma unroll
     for (int k = 0; k < KT; ++k)
-        t.dd[k] = tt[7 * KT + k];
+    {
+        t.ent[k] = tt[k * 8 + DCP_T_ENTRY];
+        t.mi[k] = tt[k * 8 + DCP_T_MI];
+        t.ii[k] = tt[k * 8 + DCP_T_II];
+    }
+#pragma unroll
+    for (int k = 1; k <= KT; ++k)
+    {
+        t.mm[k] = tt[k * 8 + DCP_T_MM];
+        t.im[k] = tt[k * 8 + DCP_T_IM];
+        t.dm[k] = tt[k * 8 + DCP_T_DM];
+        t.md[k] = tt[k * 8 + DCP_T_MD];
+        t.dd[k] = tt[k * 8 + DCP_T_DD];
+    }
+    t.mm[0] = t.im[0] = t.dm[0] = t.md[0] = t.dd[0] = 0.0f; // unused: node 0 takes Xm / Xd
 }
 
 // What a row needs from memory, fetched one row ahead (software pipeline):
@@ -442,51 +431,34 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         }
     }
 
-    // Two nodes (2b, 2b+1) at a time.  carry_pin / carry_d: the predecessor maximum and the D score of
-    // node 2b, produced by the block before (node 0: the previous tile's Xm / Xd).  Every candidate is
-    // (predecessor + transition) + emission in IEEE float32 exactly as before; only the transition adds
-    // are issued two per instruction.
-    float carry_pin = Xm, carry_d = Xd;
-    f2 const Bj2 = f2{Bj, Bj};
-    auto block = [&](int b, float ea0, float ea1, float ea2, float ea3, float ea4, float eb0, float eb1, float eb2,
-                     float eb3, float eb4) {
-        int const k0 = 2 * b, k1 = 2 * b + 1;
-        float const m0 = mx5(s.P[s1][k0] + ea0, s.P[s2][k0] + ea1, s.P[s3][k0] + ea2, s.P[s4][k0] + ea3, s.P[s5][k0] + ea4);
-        float const m1 = mx5(s.P[s1][k1] + eb0, s.P[s2][k1] + eb1, s.P[s3][k1] + eb2, s.P[s4][k1] + eb3, s.P[s5][k1] + eb4);
-        float const i0 = mx5(s.Q[s1][k0] + eI[0], s.Q[s2][k0] + eI[1], s.Q[s3][k0] + eI[2], s.Q[s4][k0] + eI[3],
-                             s.Q[s5][k0] + eI[4]);
-        float const i1 = mx5(s.Q[s1][k1] + eI[0], s.Q[s2][k1] + eI[1], s.Q[s3][k1] + eI[2], s.Q[s4][k1] + eI[3],
-                             s.Q[s5][k1] + eI[4]);
-        f2 const Mp = f2{m0, m1}, Ip = f2{i0, i1};
-        // Q of both nodes
-        f2 const q1 = Mp + tr.mi[b], q2 = Ip + tr.ii[b];
-        s.Q[PH][k0] = fmaxf(q1.x, q2.x);
-        s.Q[PH][k1] = fmaxf(q1.y, q2.y);
-        // delete chain: D of nodes 2b+1 and 2b+2
-        f2 const mdp = Mp + tr.md[b];
-        float const d0 = carry_d;
-        float const d1 = fmaxf(mdp.x, d0 + tr.dd[k0]);
-        float const d2 = fmaxf(mdp.y, d1 + tr.dd[k1]);
-        f2 const Dp = f2{d0, d1};
-        // predecessor maxima entering nodes 2b+1 and 2b+2
-        f2 const a1 = Mp + tr.mm[b], a2 = Ip + tr.im[b], a3 = Dp + tr.dm[b];
-        float const pin1 = mx3(a1.x, a2.x, a3.x);
-        float const pin2 = mx3(a1.y, a2.y, a3.y);
-        // P of both nodes
-        f2 const c = Bj2 + tr.ent[b];
-        s.P[PH][k0] = fmaxf(c.x, carry_pin);
-        s.P[PH][k1] = fmaxf(c.y, pin1);
-        E = mx3(E, m0, d0);
-        E = mx3(E, m1, d1);
-        carry_pin = pin2;
-        carry_d = d2;
+    float pm = ni, pi = ni, pd = ni; // node k-1 of this row
+    auto node = [&](int k, float e0, float e1, float e2, float e3, float e4) {
+        float const m = mx5(s.P[s1][k] + e0, s.P[s2][k] + e1, s.P[s3][k] + e2, s.P[s4][k] + e3,
+                            s.P[s5][k] + e4);
+        float const iv = mx5(s.Q[s1][k] + eI[0], s.Q[s2][k] + eI[1], s.Q[s3][k] + eI[2],
+                             s.Q[s4][k] + eI[3], s.Q[s5][k] + eI[4]);
+        float d, pin;
+        if (k == 0)
+        {
+            d = Xd;
+            pin = Xm;
+        }
+        else
+        {
+            d = fmaxf(pm + tr.md[k], pd + tr.dd[k]);
+            pin = mx3(pm + tr.mm[k], pi + tr.im[k], pd + tr.dm[k]);
+        }
+        E = mx3(E, m, d);
+        s.P[PH][k] = fmaxf(Bj + tr.ent[k], pin);
+        s.Q[PH][k] = fmaxf(m + tr.mi[k], iv + tr.ii[k]);
+        pm = m, pi = iv, pd = d;
     };
 
     // group 0 from the prefetched registers
-    block(0, in.e0[0].x, in.e0[1].x, in.e0[2].x, in.e0[3].x, in.e0[4].x, in.e0[0].y, in.e0[1].y, in.e0[2].y,
-          in.e0[3].y, in.e0[4].y);
-    block(1, in.e0[0].z, in.e0[1].z, in.e0[2].z, in.e0[3].z, in.e0[4].z, in.e0[0].w, in.e0[1].w, in.e0[2].w,
-          in.e0[3].w, in.e0[4].w);
+    node(0, in.e0[0].x, in.e0[1].x, in.e0[2].x, in.e0[3].x, in.e0[4].x);
+    node(1, in.e0[0].y, in.e0[1].y, in.e0[2].y, in.e0[3].y, in.e0[4].y);
+    node(2, in.e0[0].z, in.e0[1].z, in.e0[2].z, in.e0[3].z, in.e0[4].z);
+    node(3, in.e0[0].w, in.e0[1].w, in.e0[2].w, in.e0[3].w, in.e0[4].w);
 
     // fetch row j+D's boundary into its ring slot (slot PH itself when D == 5).  The slot's
     // old values died in node 0; the empty asm ties the load's address to group 0's E so the
@@ -529,21 +501,23 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     for (int g = 1; g < G; ++g)
     {
         float4 const *eg = e[g - 1];
-        block(2 * g + 0, eg[0].x, eg[1].x, eg[2].x, eg[3].x, eg[4].x, eg[0].y, eg[1].y, eg[2].y, eg[3].y, eg[4].y);
-        block(2 * g + 1, eg[0].z, eg[1].z, eg[2].z, eg[3].z, eg[4].z, eg[0].w, eg[1].w, eg[2].w, eg[3].w, eg[4].w);
+        node(4 * g + 0, eg[0].x, eg[1].x, eg[2].x, eg[3].x, eg[4].x);
+        node(4 * g + 1, eg[0].y, eg[1].y, eg[2].y, eg[3].y, eg[4].y);
+        node(4 * g + 2, eg[0].z, eg[1].z, eg[2].z, eg[3].z, eg[4].z);
+        node(4 * g + 3, eg[0].w, eg[1].w, eg[2].w, eg[3].w, eg[4].w);
     }
 
     if constexpr (!kRecomputeB && !FIRST)
     {
-        asm volatile("" : "+v"(off) : "v"(carry_d));
+        asm volatile("" : "+v"(off) : "v"(pm));
         ring_fetch_b<FIRST>(ring, (PH + D) % 5, pB + D * NT, off);
     }
 
     if constexpr (!LAST)
     {
-        // edges into the next tile's first node: what the last block carried out
-        float const oXm = carry_pin;
-        float const oXd = carry_d;
+        // edges into the next tile's first node
+        float const oXm = mx3(pm + tr.mm[KT], pi + tr.im[KT], pd + tr.dm[KT]);
+        float const oXd = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
         if constexpr (OUT == IO_LDS)
         {
             compiler_fence(); // not above the free-slot check of this row
@@ -624,7 +598,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         float const B0 = 0.0f + xt.SB;
 #pragma unroll
         for (int k = 0; k < KT; ++k)
-            s.P[0][k] = B0 + (k & 1 ? tr.ent[k / 2].y : tr.ent[k / 2].x);
+            s.P[0][k] = B0 + tr.ent[k];
         s.PN[0] = 0.0f + xt.SN;
         s.PR[0] = 0.0f;
     }
@@ -729,30 +703,6 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
             if (last > lk.seen + kRD) lk.seen = ring_wait(lk, last - kRD + kRingHyst);
         }
     };
-    // The prologue's loads (rows 1..D of the boundary planes, the first sequence words) are drained ONCE
-    // here.  The counted s_waitcnt at the top of a row assumes the steady state (D - 1 rows of VMEM
-    // operations in flight); on the path from the prologue into the loop that count does not cover
-    // row 1's own values, the compiler's scoreboard knows it, and -- the wait being static -- it put a
-    // s_waitcnt vmcnt(0) into the loop body that drained the three-row HBM prefetch every fifth row
-    // (round 3, first packed-add build: 2760 ms instead of 2450).  With nothing pending at the loop
-    // header the merged state is the back edge's and no such wait is generated.
-    // Spill reloads are VMEM operations too (scratch_load): a value the allocator reloads between this
-    // drain and the loop would put the static wait right back.  The empty asm statements make every value
-    // that is live into the loop sit in a register here, i.e. be reloaded BEFORE the drain.
-#pragma unroll
-    for (int h = 0; h < 5; ++h)
-    {
-#pragma unroll
-        for (int k = 0; k < KT; k += 8)
-            asm volatile("" : "+v"(s.P[h][k]), "+v"(s.P[h][k + 1]), "+v"(s.P[h][k + 2]), "+v"(s.P[h][k + 3]),
-                         "+v"(s.P[h][k + 4]), "+v"(s.P[h][k + 5]), "+v"(s.P[h][k + 6]), "+v"(s.P[h][k + 7]),
-                         "+v"(s.Q[h][k]), "+v"(s.Q[h][k + 1]), "+v"(s.Q[h][k + 2]), "+v"(s.Q[h][k + 3]),
-                         "+v"(s.Q[h][k + 4]), "+v"(s.Q[h][k + 5]), "+v"(s.Q[h][k + 6]), "+v"(s.Q[h][k + 7]));
-        asm volatile("" : "+v"(s.PN[h]), "+v"(s.PR[h]), "+v"(s.PJ[h]), "+v"(s.PC[h]), "+v"(ring.Xm[h]), "+v"(ring.Xd[h]),
-                     "+v"(ring.Em[h]), "+v"(ring.B[h]), "+v"(wq[h]), "+v"(in.eI[h]), "+v"(in.eN[h]));
-    }
-    asm volatile("" : "+v"(off), "+v"(wn), "+v"(go.a[0]), "+v"(go.a[1]), "+v"(go.a[2]), "+v"(go.a[3]), "+v"(go.a[4]));
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     while (j + 4 <= Lwave)
     {
         ring_sync(5u);
@@ -844,7 +794,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             }
             __syncthreads();
             if (Lwave == 0u) continue; // no lane of this wavefront has a query
-            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * KT * 8);
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
 #if DCP_QLANE_DIAG & 4
 #define QL_DIAG4_TILE , (t & 1u)
@@ -985,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
             flag_store((lds_uint *)(lk.base + lk.my_flag + tid * 4u), 0u); // row counters restart with every step
             __syncthreads();
             if (Lwave == 0u || !mine) continue;
-            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * KT * 8);
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0u, last = t + 1u == T;
 #if DCP_QLANE_DIAG & 4
 #error "the two-stage kernel has no DIAG=4 build"
@@ -1105,7 +1055,7 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
             }
             compiler_fence(); // the sweep's gathers stay behind the image's stores (same wavefront: LDS keeps the order)
             if (Lwave == 0u) continue;
-            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * KT * 8);
+            cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
 #define QLW_SWEEP(F, L_)                                                                                  \
     ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{})

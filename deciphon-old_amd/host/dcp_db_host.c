@@ -15,18 +15,138 @@
 #include "deciphon_host.h"
 #include "host_internal.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
 #define fail dcp_host_fail
 
-/* ---- db_reader (src/db/reader.c) --------------------------------------------------------------------- */
+/* ---- the header, as data -------------------------------------------------------------------------------
+ * One table says what the header map holds -- key, wire type, where the value lives in a protein database
+ * object, and the test it must pass.  ONE reader and ONE writer walk it; the per-field entry points of
+ * the reference's API (db_reader_unpack_*, db_writer_pack_*: src/db/reader.c:25-79, src/db/writer.c:45-93)
+ * are single-row walks.  Row order = file order (the reference reads the keys positionally). */
+enum hdr_wire
+{
+    W_UINT,  /* MessagePack unsigned */
+    W_F32,   /* float32 */
+    W_ABC,   /* imm_abc value (map) */
+    W_SIZES, /* 1darray of uint32: bytes of every profile */
+};
+
+enum hdr_row
+{
+    H_MAGIC,
+    H_TYPEID,
+    H_FLOAT_SIZE,
+    H_ENTRY_DIST,
+    H_EPSILON,
+    H_NUCLT,
+    H_AMINO,
+    H_SIZES,
+    H_ROWS
+};
+
+/* what the rows read into / write from */
+struct hdr_values
+{
+    unsigned magic, typeid_, float_size, entry_dist;
+    float epsilon;
+    struct imm_abc *nuclt, *amino; /* only the rows W_ABC touch them */
+    struct db_reader *reader;      /* W_SIZES fills nprofiles / profile_sizes */
+    unsigned want_typeid;
+};
+
+static bool ok_magic(struct hdr_values const *v) { return v->magic == MAGIC_NUMBER; }
+static bool ok_typeid(struct hdr_values const *v) { return v->typeid_ == v->want_typeid; }
+static bool ok_float_size(struct hdr_values const *v) { return v->float_size == IMM_FLOAT_BYTES; }
+static bool ok_entry_dist(struct hdr_values const *v)
+{
+    return v->entry_dist > ENTRY_DIST_NULL && v->entry_dist <= ENTRY_DIST_OCCUPANCY;
+}
+static bool ok_epsilon(struct hdr_values const *v) { return v->epsilon >= 0 && v->epsilon <= 1; }
+static bool ok_nuclt(struct hdr_values const *v) { return v->nuclt->size == IMM_NUCLT_SIZE; }
+static bool ok_amino(struct hdr_values const *v) { return v->amino->size == IMM_AMINO_SIZE; }
+static bool ok_sizes(struct hdr_values const *v) { return v->reader->nprofiles <= MAX_NPROFILES; }
+
+static struct
+{
+    char const *key;
+    enum hdr_wire wire;
+    size_t at; /* offset of the scalar in hdr_values (W_UINT, W_F32) */
+    bool (*valid)(struct hdr_values const *);
+} const hdr_schema[H_ROWS] = {
+    [H_MAGIC] = {"magic_number", W_UINT, offsetof(struct hdr_values, magic), ok_magic},
+    [H_TYPEID] = {"profile_typeid", W_UINT, offsetof(struct hdr_values, typeid_), ok_typeid},
+    [H_FLOAT_SIZE] = {"float_size", W_UINT, offsetof(struct hdr_values, float_size), ok_float_size},
+    [H_ENTRY_DIST] = {"entry_dist", W_UINT, offsetof(struct hdr_values, entry_dist), ok_entry_dist},
+    [H_EPSILON] = {"epsilon", W_F32, offsetof(struct hdr_values, epsilon), ok_epsilon},
+    [H_NUCLT] = {"abc", W_ABC, 0, ok_nuclt},
+    [H_AMINO] = {"amino", W_ABC, 0, ok_amino},
+    [H_SIZES] = {"profile_sizes", W_SIZES, 0, ok_sizes},
+};
+
+/* rows [first, last] from the file into *v: a key or value that cannot be read is RC_EIO, a value that
+ * fails its row's test RC_EINVAL */
+static enum rc hdr_read(struct lip_file *file, struct hdr_values *v, enum hdr_row first, enum hdr_row last)
+{
+    for (int r = first; r <= (int)last; ++r)
+    {
+        char const *key = hdr_schema[r].key;
+        void *slot = (char *)v + hdr_schema[r].at;
+        bool got = expect_map_key(file, key);
+        if (got) switch (hdr_schema[r].wire)
+            {
+            case W_UINT: got = lip_read_unsigned(file, slot); break;
+            case W_F32: got = lip_read_f32(file, slot); break;
+            case W_ABC: got = imm_abc_unpack(r == H_NUCLT ? v->nuclt : v->amino, file) == IMM_OK; break;
+            case W_SIZES:
+            {
+                struct db_reader *db = v->reader;
+                enum lip_1darray_type ty = 0;
+                got = lip_read_1darray_size_type(file, &db->nprofiles, &ty);
+                if (got && ty != LIP_1DARRAY_UINT32) return fail(RC_EINVAL, "header field %s: not a uint32 array", key);
+                if (got && !hdr_schema[r].valid(v)) return fail(RC_EINVAL, "header field %s: %u profiles is too many", key, db->nprofiles);
+                if (got)
+                {
+                    db->profile_sizes = malloc(sizeof *db->profile_sizes * (db->nprofiles ? db->nprofiles : 1));
+                    if (!db->profile_sizes) return fail(RC_ENOMEM, "header field %s: out of memory", key);
+                    got = lip_read_1darray_u32_data(file, db->nprofiles, db->profile_sizes);
+                    if (!got)
+                    {
+                        free(db->profile_sizes);
+                        db->profile_sizes = NULL;
+                    }
+                }
+                break;
+            }
+            }
+        if (!got) return fail(RC_EIO, "header field %s: cannot be read", key);
+        if (!hdr_schema[r].valid(v)) return fail(RC_EINVAL, "header field %s: value not accepted", key);
+    }
+    return RC_OK;
+}
+
+/* row r from *v to `out` (key, then value) */
+static enum rc hdr_write(struct lip_file *out, struct hdr_values const *v, enum hdr_row r)
+{
+    void const *slot = (char const *)v + hdr_schema[r].at;
+    bool ok = lip_write_cstr(out, hdr_schema[r].key);
+    if (ok) switch (hdr_schema[r].wire)
+        {
+        case W_UINT: ok = lip_write_uint(out, *(unsigned const *)slot); break;
+        case W_F32: ok = lip_write_f32(out, *(float const *)slot); break;
+        case W_ABC: ok = imm_abc_pack(r == H_NUCLT ? v->nuclt : v->amino, out) == IMM_OK; break;
+        case W_SIZES: ok = false; break; /* written by db_writer_close from the sizes it collected */
+        }
+    return ok ? RC_OK : fail(RC_EIO, "header field %s: cannot be written", hdr_schema[r].key);
+}
+
+/* ---- db_reader (include/deciphon/db/reader.h) -------------------------------------------------------- */
 enum rc db_reader_open(struct db_reader *db, FILE *fp)
 {
-    db->nprofiles = 0;
-    db->profile_sizes = NULL;
-    db->profile_typeid = PROFILE_NULL;
+    *db = (struct db_reader){.nprofiles = 0, .profile_sizes = NULL, .profile_typeid = PROFILE_NULL};
     lip_file_init(&db->file, fp);
     return RC_OK;
 }
@@ -37,170 +157,92 @@ void db_reader_close(struct db_reader *db)
     db->profile_sizes = NULL;
 }
 
-enum rc db_reader_unpack_magic_number(struct db_reader *db)
+static enum rc reader_row(struct db_reader *db, enum hdr_row r, unsigned want_typeid)
 {
-    if (!expect_map_key(&db->file, "magic_number")) return fail(RC_EIO, "read key");
-    unsigned number = 0;
-    if (!lip_read_unsigned(&db->file, &number)) return fail(RC_EIO, "read magic number");
-    return number != MAGIC_NUMBER ? fail(RC_EINVAL, "invalid magic number") : RC_OK;
+    struct hdr_values v = {.reader = db, .want_typeid = want_typeid};
+    enum rc rc = hdr_read(&db->file, &v, r, r);
+    if (r == H_TYPEID) db->profile_typeid = (enum profile_typeid)v.typeid_;
+    return rc;
 }
+enum rc db_reader_unpack_magic_number(struct db_reader *db) { return reader_row(db, H_MAGIC, 0); }
+enum rc db_reader_unpack_profile_typeid(struct db_reader *db, enum profile_typeid typeid) { return reader_row(db, H_TYPEID, typeid); }
+enum rc db_reader_unpack_float_size(struct db_reader *db) { return reader_row(db, H_FLOAT_SIZE, 0); }
+enum rc db_reader_unpack_profile_sizes(struct db_reader *db) { return reader_row(db, H_SIZES, 0); }
 
-enum rc db_reader_unpack_profile_typeid(struct db_reader *db, enum profile_typeid typeid)
-{
-    if (!expect_map_key(&db->file, "profile_typeid")) return fail(RC_EIO, "read key");
-    unsigned v = 0;
-    if (!lip_read_unsigned(&db->file, &v)) return fail(RC_EIO, "read typeid");
-    db->profile_typeid = (enum profile_typeid)v;
-    if (db->profile_typeid != typeid) return fail(RC_EINVAL, "invalid typeid");
-    return RC_OK;
-}
-
-enum rc db_reader_unpack_float_size(struct db_reader *db)
-{
-    if (!expect_map_key(&db->file, "float_size")) return fail(RC_EIO, "read key");
-    unsigned size = 0;
-    if (!lip_read_unsigned(&db->file, &size)) return fail(RC_EIO, "read float size");
-    return size != IMM_FLOAT_BYTES ? fail(RC_EINVAL, "invalid float size") : RC_OK;
-}
-
-enum rc db_reader_unpack_profile_sizes(struct db_reader *db)
-{
-    if (!expect_map_key(&db->file, "profile_sizes")) return fail(RC_EIO, "read key");
-    enum lip_1darray_type type = 0;
-    if (!lip_read_1darray_size_type(&db->file, &db->nprofiles, &type)) return fail(RC_EIO, "read array");
-    if (type != LIP_1DARRAY_UINT32) return fail(RC_EINVAL, "invalid type");
-    if (db->nprofiles > MAX_NPROFILES) return fail(RC_EINVAL, "too many profiles");
-    db->profile_sizes = malloc(sizeof *db->profile_sizes * (db->nprofiles ? db->nprofiles : 1));
-    if (!db->profile_sizes) return fail(RC_ENOMEM, "allocate memory");
-    if (!lip_read_1darray_u32_data(&db->file, db->nprofiles, db->profile_sizes))
-    {
-        free(db->profile_sizes);
-        db->profile_sizes = NULL;
-        return fail(RC_EIO, "read array");
-    }
-    return RC_OK;
-}
-
-/* ---- protein_db_reader (src/db/protein_reader.c:40-82) ------------------------------------------------- */
+/* ---- protein_db_reader (include/deciphon/db/protein_reader.h): root map, then every row of the table --- */
 enum rc protein_db_reader_open(struct protein_db_reader *db, FILE *fp)
 {
     enum rc rc = db_reader_open(&db->super, fp);
     if (rc) return rc;
     struct lip_file *file = &db->super.file;
-    if (!expect_map_size(file, 2)) return fail(RC_EIO, "read map");
-    if (!expect_map_key(file, "header")) return fail(RC_EIO, "read key");
-    if (!expect_map_size(file, 8)) return fail(RC_EIO, "read map");
-
-    if ((rc = db_reader_unpack_magic_number(&db->super))) goto cleanup;
-    if ((rc = db_reader_unpack_profile_typeid(&db->super, PROFILE_PROTEIN))) goto cleanup;
-    if ((rc = db_reader_unpack_float_size(&db->super))) goto cleanup;
-
-    unsigned edist = 0;
-    if (!expect_map_key(file, "entry_dist") || !lip_read_unsigned(file, &edist))
+    if (!expect_map_size(file, 2) || !expect_map_key(file, "header") || !expect_map_size(file, H_ROWS))
+        return fail(RC_EIO, "not a database: root map / header map");
+    struct hdr_values v = {.nuclt = &db->nuclt.super, .amino = &db->amino.super, .reader = &db->super,
+                           .want_typeid = PROFILE_PROTEIN};
+    rc = hdr_read(file, &v, H_MAGIC, H_SIZES);
+    db->super.profile_typeid = (enum profile_typeid)v.typeid_;
+    if (rc)
     {
-        rc = fail(RC_EIO, "read entry dist");
-        goto cleanup;
+        db_reader_close(&db->super);
+        return rc;
     }
-    if (edist <= ENTRY_DIST_NULL || edist > ENTRY_DIST_OCCUPANCY)
-    {
-        rc = fail(RC_EINVAL, "invalid entry dist");
-        goto cleanup;
-    }
-    db->cfg.entry_dist = (enum entry_dist)edist;
-    if (!expect_map_key(file, "epsilon") || !lip_read_f32(file, &db->cfg.epsilon))
-    {
-        rc = fail(RC_EIO, "read epsilon");
-        goto cleanup;
-    }
-    if (!(db->cfg.epsilon >= 0 && db->cfg.epsilon <= 1))
-    {
-        rc = fail(RC_EINVAL, "invalid epsilon");
-        goto cleanup;
-    }
-    if (!expect_map_key(file, "abc") || imm_abc_unpack(&db->nuclt.super, file))
-    {
-        rc = fail(RC_EIO, "read nuclt");
-        goto cleanup;
-    }
-    if (!expect_map_key(file, "amino") || imm_abc_unpack(&db->amino.super, file))
-    {
-        rc = fail(RC_EIO, "read amino");
-        goto cleanup;
-    }
-    /* the engine is built for 4-letter nucleotide and 20-letter amino alphabets */
-    if (db->nuclt.super.size != IMM_NUCLT_SIZE || db->amino.super.size != IMM_AMINO_SIZE)
-    {
-        rc = fail(RC_EINVAL, "unsupported alphabet sizes %u / %u", db->nuclt.super.size, db->amino.super.size);
-        goto cleanup;
-    }
+    db->cfg = protein_cfg((enum entry_dist)v.entry_dist, v.epsilon);
     imm_nuclt_code_init(&db->code, &db->nuclt);
-    if ((rc = db_reader_unpack_profile_sizes(&db->super))) goto cleanup;
-    return rc;
-
-cleanup:
-    db_reader_close(&db->super);
-    return rc;
+    return RC_OK;
 }
 
-/* ---- db_writer (src/db/writer.c): header items and profiles go to temporary files first, because the
- * header's map size and profile_sizes are only known at close ------------------------------------------- */
-static void destroy_tempfiles(struct db_writer *db)
+/* ---- db_writer (include/deciphon/db/writer.h) ------------------------------------------------------------
+ * The header's item count and profile_sizes are known only at close, so header items and sizes are
+ * collected in memory streams (fmemopen: a few hundred bytes of header, 4 bytes per profile) and only the
+ * profiles -- gigabytes for a Pfam-sized database -- in a temporary file.  The three lip_file members are
+ * the reference's; a writer owns nothing outside them, so writers are independent of each other. */
+enum
 {
-    if (db->tmp.header.fp) fclose(db->tmp.header.fp);
-    if (db->tmp.profile_sizes.fp) fclose(db->tmp.profile_sizes.fp);
-    if (db->tmp.profiles.fp) fclose(db->tmp.profiles.fp);
-    db->tmp.header.fp = db->tmp.profile_sizes.fp = db->tmp.profiles.fp = NULL;
-}
+    HDR_STAGE_BYTES = 1 << 16,
+    SIZES_STAGE_BYTES = 4 * (MAX_NPROFILES + 1),
+};
 
-static enum rc copy_stream(FILE *dst, FILE *src)
+static void writer_drop(struct db_writer *db)
 {
-    char buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, src)) > 0)
-        if (fwrite(buf, 1, n, dst) != n) return fail(RC_EIO, "failed to write");
-    return ferror(src) ? fail(RC_EIO, "failed to read") : RC_OK;
+    FILE **fps[3] = {&db->tmp.header.fp, &db->tmp.profile_sizes.fp, &db->tmp.profiles.fp};
+    for (int i = 0; i < 3; ++i)
+        if (*fps[i])
+        {
+            fclose(*fps[i]);
+            *fps[i] = NULL;
+        }
 }
 
 enum rc db_writer_open(struct db_writer *db, FILE *fp)
 {
-    db->nprofiles = 0;
-    db->header_size = 0;
+    db->nprofiles = db->header_size = 0;
     lip_file_init(&db->file, fp);
-    lip_file_init(&db->tmp.header, tmpfile());
-    lip_file_init(&db->tmp.profile_sizes, tmpfile());
+    lip_file_init(&db->tmp.header, fmemopen(NULL, HDR_STAGE_BYTES, "w+"));
+    lip_file_init(&db->tmp.profile_sizes, fmemopen(NULL, SIZES_STAGE_BYTES, "w+"));
     lip_file_init(&db->tmp.profiles, tmpfile());
-    if (!db->tmp.header.fp || !db->tmp.profile_sizes.fp || !db->tmp.profiles.fp)
-    {
-        destroy_tempfiles(db);
-        return fail(RC_EIO, "create tmpfile");
-    }
-    return RC_OK;
+    if (db->tmp.header.fp && db->tmp.profile_sizes.fp && db->tmp.profiles.fp) return RC_OK;
+    writer_drop(db);
+    return fail(RC_EIO, "cannot create the writer's staging streams");
 }
 
+static enum rc writer_row(struct db_writer *db, enum hdr_row r, struct hdr_values const *v)
+{
+    enum rc rc = hdr_write(&db->tmp.header, v, r);
+    if (!rc) db->header_size++;
+    return rc;
+}
 enum rc db_writer_pack_magic_number(struct db_writer *db)
 {
-    if (!lip_write_cstr(&db->tmp.header, "magic_number") || !lip_write_int(&db->tmp.header, MAGIC_NUMBER))
-        return fail(RC_EIO, "write magic number");
-    db->header_size++;
-    return RC_OK;
+    return writer_row(db, H_MAGIC, &(struct hdr_values){.magic = MAGIC_NUMBER});
 }
-
 enum rc db_writer_pack_profile_typeid(struct db_writer *db, int profile_typeid)
 {
-    if (!lip_write_cstr(&db->tmp.header, "profile_typeid") || !lip_write_int(&db->tmp.header, profile_typeid))
-        return fail(RC_EIO, "write profile_typeid");
-    db->header_size++;
-    return RC_OK;
+    return writer_row(db, H_TYPEID, &(struct hdr_values){.typeid_ = (unsigned)profile_typeid});
 }
-
 enum rc db_writer_pack_float_size(struct db_writer *db)
 {
-    if (!lip_write_cstr(&db->tmp.header, "float_size") || !lip_write_int(&db->tmp.header, IMM_FLOAT_BYTES))
-        return fail(RC_EIO, "write float size");
-    db->header_size++;
-    return RC_OK;
+    return writer_row(db, H_FLOAT_SIZE, &(struct hdr_values){.float_size = IMM_FLOAT_BYTES});
 }
-
 enum rc db_writer_pack_header_item(struct db_writer *db, pack_header_item_func_t pack_header_item, void const *arg)
 {
     db->header_size++;
@@ -209,93 +251,62 @@ enum rc db_writer_pack_header_item(struct db_writer *db, pack_header_item_func_t
 
 enum rc db_writer_pack_profile(struct db_writer *db, pack_profile_func_t pack_profile, void const *arg)
 {
-    long const start = ftell(db->tmp.profiles.fp);
-    if (start < 0) return fail(RC_EIO, "ftell");
-    enum rc rc = pack_profile(&db->tmp.profiles, arg);
+    FILE *fp = db->tmp.profiles.fp;
+    long const before = ftell(fp);
+    enum rc rc = before < 0 ? fail(RC_EIO, "profile staging file") : pack_profile(&db->tmp.profiles, arg);
     if (rc) return rc;
-    long const end = ftell(db->tmp.profiles.fp);
-    if (end < 0) return fail(RC_EIO, "ftell");
-    if ((uint64_t)(end - start) > UINT32_MAX) return fail(RC_EFAIL, "profile is too large");
-    if (!lip_write_int(&db->tmp.profile_sizes, (unsigned)(end - start))) return fail(RC_EIO, "write profile size");
+    long const after = ftell(fp);
+    if (after < before) return fail(RC_EIO, "profile staging file");
+    if ((uint64_t)(after - before) > UINT32_MAX) return fail(RC_EFAIL, "a profile of %ld bytes does not fit profile_sizes", after - before);
+    uint32_t const bytes = (uint32_t)(after - before); /* raw: becomes one element of the 1darray at close */
+    if (fwrite(&bytes, sizeof bytes, 1, db->tmp.profile_sizes.fp) != 1) return fail(RC_EIO, "profile size list");
     db->nprofiles++;
     return RC_OK;
+}
+
+/* the first `limit` bytes of `src` (SIZE_MAX: all of it) appended to `dst` */
+static bool copy_bytes(FILE *dst, FILE *src, size_t limit)
+{
+    static _Thread_local char buf[1 << 16];
+    rewind(src);
+    while (limit)
+    {
+        size_t const want = limit < sizeof buf ? limit : sizeof buf, n = fread(buf, 1, want, src);
+        if (n == 0) break;
+        if (fwrite(buf, 1, n, dst) != n) return false;
+        limit -= n;
+    }
+    return !ferror(src) && (limit == 0 || limit > ((size_t)-1) / 2);
 }
 
 enum rc db_writer_close(struct db_writer *db, bool successfully)
 {
     enum rc rc = RC_OK;
-    if (!successfully) goto cleanup;
-    struct lip_file *file = &db->file;
-    if (!lip_write_map_size(file, 2))
+    if (successfully)
     {
-        rc = fail(RC_EIO, "write root map size");
-        goto cleanup;
-    }
-    /* "header": the items collected so far + profile_sizes */
-    if (!lip_write_cstr(file, "header") || !lip_write_map_size(file, db->header_size + 1))
-    {
-        rc = fail(RC_EIO, "write header");
-        goto cleanup;
-    }
-    rewind(db->tmp.header.fp);
-    if ((rc = copy_stream(file->fp, db->tmp.header.fp))) goto cleanup;
-    if (!lip_write_cstr(file, "profile_sizes") || !lip_write_1darray_size_type(file, db->nprofiles, LIP_1DARRAY_UINT32))
-    {
-        rc = fail(RC_EIO, "write profile sizes");
-        goto cleanup;
-    }
-    rewind(db->tmp.profile_sizes.fp);
-    db->tmp.profile_sizes.error = false;
-    for (unsigned i = 0; i < db->nprofiles; ++i)
-    {
-        unsigned size = 0;
-        if (!lip_read_unsigned(&db->tmp.profile_sizes, &size) || !lip_write_1darray_u32_item(file, size))
+        struct lip_file *out = &db->file;
+        long const hdr_bytes = ftell(db->tmp.header.fp);
+        /* root: {"header": {items..., "profile_sizes": [...]}, "profiles": [...]} */
+        bool ok = hdr_bytes >= 0 && lip_write_map_size(out, 2) && lip_write_cstr(out, "header") &&
+                  lip_write_map_size(out, db->header_size + 1) && copy_bytes(out->fp, db->tmp.header.fp, (size_t)hdr_bytes);
+        ok = ok && ftell(db->tmp.profile_sizes.fp) == (long)((size_t)db->nprofiles * sizeof(uint32_t)) &&
+             lip_write_cstr(out, hdr_schema[H_SIZES].key) &&
+             lip_write_1darray_size_type(out, db->nprofiles, LIP_1DARRAY_UINT32);
+        if (ok) rewind(db->tmp.profile_sizes.fp);
+        for (unsigned i = 0; ok && i < db->nprofiles; ++i)
         {
-            rc = fail(RC_EIO, "write profile sizes");
-            goto cleanup;
+            uint32_t bytes;
+            ok = fread(&bytes, sizeof bytes, 1, db->tmp.profile_sizes.fp) == 1 && lip_write_1darray_u32_item(out, bytes);
         }
+        ok = ok && lip_write_cstr(out, "profiles") && lip_write_array_size(out, db->nprofiles) &&
+             copy_bytes(out->fp, db->tmp.profiles.fp, (size_t)-1) && fflush(out->fp) == 0;
+        if (!ok) rc = fail(RC_EIO, "cannot write the database file");
     }
-    /* "profiles" */
-    if (!lip_write_cstr(file, "profiles") || !lip_write_array_size(file, db->nprofiles))
-    {
-        rc = fail(RC_EIO, "write profiles");
-        goto cleanup;
-    }
-    rewind(db->tmp.profiles.fp);
-    if ((rc = copy_stream(file->fp, db->tmp.profiles.fp))) goto cleanup;
-    if (fflush(file->fp)) rc = fail(RC_EIO, "failed to flush");
-
-cleanup:
-    destroy_tempfiles(db);
+    writer_drop(db);
     return rc;
 }
 
-/* ---- protein_db_writer (src/db/protein_writer.c) -------------------------------------------------------- */
-static enum rc pack_entry_dist_cb(struct lip_file *file, void const *arg)
-{
-    return lip_write_cstr(file, "entry_dist") && lip_write_int(file, *(enum entry_dist const *)arg)
-               ? RC_OK
-               : fail(RC_EIO, "write entry dist");
-}
-static enum rc pack_epsilon_cb(struct lip_file *file, void const *arg)
-{
-    return lip_write_cstr(file, "epsilon") && lip_write_float(file, *(imm_float const *)arg)
-               ? RC_OK
-               : fail(RC_EIO, "write epsilon");
-}
-static enum rc pack_nuclt_cb(struct lip_file *file, void const *arg)
-{
-    return lip_write_cstr(file, "abc") && !imm_abc_pack(&((struct imm_nuclt const *)arg)->super, file)
-               ? RC_OK
-               : fail(RC_EIO, "write nuclt abc");
-}
-static enum rc pack_amino_cb(struct lip_file *file, void const *arg)
-{
-    return lip_write_cstr(file, "amino") && !imm_abc_pack(&((struct imm_amino const *)arg)->super, file)
-               ? RC_OK
-               : fail(RC_EIO, "write amino abc");
-}
-
+/* ---- protein_db_writer (include/deciphon/db/protein_writer.h) ------------------------------------------- */
 enum rc protein_db_writer_open(struct protein_db_writer *db, FILE *fp, struct imm_amino const *amino,
                                struct imm_nuclt const *nuclt, struct protein_cfg cfg)
 {
@@ -305,17 +316,12 @@ enum rc protein_db_writer_open(struct protein_db_writer *db, FILE *fp, struct im
     db->nuclt = *nuclt;
     imm_nuclt_code_init(&db->code, &db->nuclt);
     db->cfg = cfg;
-    if ((rc = db_writer_pack_magic_number(&db->super))) goto cleanup;
-    if ((rc = db_writer_pack_profile_typeid(&db->super, PROFILE_PROTEIN))) goto cleanup;
-    if ((rc = db_writer_pack_float_size(&db->super))) goto cleanup;
-    if ((rc = db_writer_pack_header_item(&db->super, pack_entry_dist_cb, &db->cfg.entry_dist))) goto cleanup;
-    if ((rc = db_writer_pack_header_item(&db->super, pack_epsilon_cb, &db->cfg.epsilon))) goto cleanup;
-    if ((rc = db_writer_pack_header_item(&db->super, pack_nuclt_cb, &db->nuclt))) goto cleanup;
-    if ((rc = db_writer_pack_header_item(&db->super, pack_amino_cb, &db->amino))) goto cleanup;
-    return rc;
-
-cleanup:
-    db_writer_close(&db->super, false);
+    struct hdr_values const v = {.magic = MAGIC_NUMBER, .typeid_ = PROFILE_PROTEIN, .float_size = IMM_FLOAT_BYTES,
+                                 .entry_dist = (unsigned)cfg.entry_dist, .epsilon = cfg.epsilon,
+                                 .nuclt = &db->nuclt.super, .amino = &db->amino.super};
+    for (int r = H_MAGIC; r < H_SIZES && !rc; ++r)
+        rc = writer_row(&db->super, (enum hdr_row)r, &v);
+    if (rc) db_writer_close(&db->super, false);
     return rc;
 }
 
@@ -387,23 +393,23 @@ static enum rc reader_setup(struct profile_reader *reader, struct db_reader *db,
     }
     reader->npartitions = nparts;
 
-    /* partition_init + partition_it (profile_reader.c:45-72): sizes, then byte offsets from
-     * profile_sizes[].  ceil-sized partitions can leave trailing empty ones whose end offset the
-     * reference never writes (stays 0): reproduced as is. */
+    /* Count-balanced partitions (profile_reader.c:45-72, xmath.h:24-30): partition i takes the next
+     * xmath_partition_size(n, nparts, i) profiles; its end offset is its start plus their bytes.  The
+     * ceil-sized shares can exhaust the profiles early: the trailing partitions are empty and -- as in the
+     * reference, which never reaches them in its loop -- their end offsets are never written (stay 0). */
     reader->partition_offset[0] = profiles_offset;
     if (!by_bytes)
     {
-        unsigned i = 0, size = 0;
-        for (unsigned j = 0; j < db->nprofiles; ++j)
+        unsigned next = 0;
+        for (unsigned i = 0; i < nparts && next < db->nprofiles; ++i)
         {
-            reader->partition_offset[i + 1] += db->profile_sizes[j];
-            if (++size >= xmath_partition_size(db->nprofiles, nparts, i))
-            {
-                reader->partition_size[i] = size;
-                reader->partition_offset[i + 1] += reader->partition_offset[i];
-                ++i;
-                size = 0;
-            }
+            unsigned const share = xmath_partition_size(db->nprofiles, nparts, i);
+            int64_t bytes = 0;
+            for (unsigned j = next; j < next + share; ++j)
+                bytes += db->profile_sizes[j];
+            reader->partition_size[i] = share;
+            reader->partition_offset[i + 1] = reader->partition_offset[i] + bytes;
+            next += share;
         }
     }
     else
