@@ -602,6 +602,21 @@ def main():
                                           + pmc.get("note", ""))
         except (OSError, ValueError, KeyError):
             pass
+        # What the VALU can do with THIS instruction mix: the row's arithmetic alone, measured in a registers-only
+        # microbenchmark (profiles/microbench/row_valu.hip; replayed like the PMC traffic).  28 ops per cell at
+        # the 2-cycle rate is not attainable for a max-plus recursion on gfx950: v_max_f32 / v_max3_f32 --
+        # a third of the ops -- and adds with an SGPR operand issue at half that rate (profiles/r03/valu_issue.txt).
+        valu_ceiling = None
+        try:
+            vc = json.load(open(os.path.join(ROOT, "profiles", "latest_valu_ceiling.json")))
+            cyc = float(vc["cycles_per_wavefront_row"])
+            at_spec = 256 * 4 * 64 * vc["nodes_per_lane"] / cyc * 2.4e9
+            valu_ceiling = {"cycles_per_wavefront_row_arithmetic_only": cyc,
+                            "gcells_per_s_at_2.4GHz": round(at_spec / 1e9, 1),
+                            "frac_of_ceiling": (round(dom_cells / (dom_ms * 1e-3) / at_spec, 4) if is_qlane else None),
+                            "source": "replayed from profiles/latest_valu_ceiling.json: " + vc["source"]}
+        except (OSError, ValueError, KeyError):
+            pass
         # analytic HBM traffic of the design, to hold against the measured figure:
         #   query lane: 12 B written + 12 B read per (row, lane, tile boundary) -- the Xm/Xd/Em planes --
         #               plus every tile image once per (profile, 256-query block)
@@ -620,6 +635,7 @@ def main():
             "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK / 1e12, 1), "unit": "Tlane-op/s",
             "frac": round(lane_ops / VALU_PEAK, 4),
             "ops_per_cell": OPS_PER_CELL,
+            "valu_only_ceiling": valu_ceiling,
             "peak_note": ("256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (spec clock); measured clock under this load: two-stage "
                           "query-lane kernel 2.23 GHz, single-stage 1.81 GHz, row sweep 2.3-2.4 GHz (profiles/r02/*pmc*)"),
             "avg_launch_ms": round(dom_ms, 3),

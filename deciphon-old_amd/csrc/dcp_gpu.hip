@@ -107,7 +107,10 @@ struct dcp_gpu_ctx
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
-    DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block transposed sequence words
+    DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block sequence planes (row windows, or packed words)
+    uint32_t wplane1 = 0;                 // word offset of the second window plane (two-stage kernel), 0 = none
+    unsigned qorder_planes = 0;           // planes the cached layout holds
+    bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
     // d_redo_n = [DCP_MAX_CLASSES counters][overflow flag]
@@ -416,6 +419,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     unsigned const KT = 4u * (unsigned)c->ql_G;
     uint64_t tile_floats = 0, ttrans_floats = 0;
     c->ql_metas.assign(nprofiles, dcp_ql_prof{});
+    c->any_exact_e = false;
     c->sum_core = c->sum_tiles = 0;
     c->max_tiles = 0;
     for (uint64_t &v : c->class_core)
@@ -433,6 +437,16 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         c->class_core[qm.cls] += m.core_size;
         c->sum_tiles += qm.ntiles;
         c->max_tiles = std::max(c->max_tiles, qm.ntiles);
+        {
+            // E(j) as the match states' maximum (dcp_qlane.hip, EM) needs MD, DD <= 0: true of every profile
+            // whose transitions are log-probabilities; any other profile is scored by the row sweep
+            float const *t8 = dcp_profile_trans8(profiles[m.pidx]);
+            bool pos = false;
+            for (unsigned k = 0; k < m.core_size && !pos; ++k)
+                pos = t8[(size_t)DCP_T_MD * m.core_size + k] > 0.0f || t8[(size_t)DCP_T_DD * m.core_size + k] > 0.0f;
+            qm.needs_exact_e = pos ? 1u : 0u;
+            c->any_exact_e = c->any_exact_e || pos;
+        }
         qm.tile_off = tile_floats;
         qm.ttrans_off = (uint32_t)ttrans_floats;
         tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
@@ -930,7 +944,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (kernel == 2)
     {
         // queries sorted by length so that the lanes of a block finish together
-        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt)
+        unsigned const nplanes = dcp_qlane_window_planes() ? (two_stage ? 2u : 1u) : 1u;
+        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt || c->qorder_planes != nplanes)
         {
             std::vector<uint32_t> ord(nq);
             for (unsigned i = 0; i < nq; ++i)
@@ -943,7 +958,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 lmax = std::max(lmax, c->seq_len[q]);
             if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
             HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            // per block of NT queries: (longest member / 16 + 3) word rows, transposed
+            // per block of NT queries: the rows of its sequence plane (dcp_qlane_plane_rows of its longest member)
             unsigned const NTq = ql_nt;
             unsigned const nqb = (nq + NTq - 1u) / NTq;
             std::vector<uint32_t> wt_off(nqb + 1u, 0u);
@@ -951,21 +966,24 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             for (unsigned b = 0; b < nqb; ++b)
             {
                 unsigned const lastq = std::min(nq, (b + 1u) * NTq) - 1u; // ascending lengths
-                tot += (uint64_t)(c->seq_len[q_begin + ord[lastq]] / 16u + 3u) * NTq;
-                if (tot > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
+                tot += (uint64_t)dcp_qlane_plane_rows(c->seq_len[q_begin + ord[lastq]]) * NTq;
+                if (tot * nplanes > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
                 wt_off[b + 1u] = (uint32_t)tot;
             }
             if (c->d_wt_off.n < nqb + 1u) HIP_TRY(c, c->d_wt_off.alloc(nqb + 1u));
-            if (c->d_words_t.n < tot) HIP_TRY(c, c->d_words_t.alloc((size_t)tot));
+            if (c->d_words_t.n < tot * nplanes) HIP_TRY(c, c->d_words_t.alloc((size_t)(tot * nplanes)));
+            c->wplane1 = nplanes > 1u ? (uint32_t)tot : 0u;
             HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off.data(), (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             dcp_qlane_args ta{};
             ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
             ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
             ta.nseqs = nq, ta.nqblocks = nqb;
+            ta.wplane1 = c->wplane1;
             if (dcp_launch_qlane_transpose(&ta, NTq, c->stream)) return c->fail(DCP_EFAIL, "no kernel for %u-query blocks", NTq);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(c->stream)); // ord / wt_off are stack-local
             c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax, c->qorder_nt = NTq;
+            c->qorder_planes = nplanes;
         }
         if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
     }
@@ -988,6 +1006,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.qorder = c->d_qorder.p;
         qa.words_t = c->d_words_t.p;
         qa.wt_off = c->d_wt_off.p;
+        qa.wplane1 = c->wplane1;
         qa.task_counter = c->d_task_counter.p;
         qa.out_null = a.out_null;
         qa.out_alt = a.out_alt;
@@ -1007,7 +1026,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.ntasks = (unsigned)ntasks;
         // redo lists: pairs whose multi-hit feedback beat B0 go to the row-sweep kernel, which
         // runs right behind the query-lane kernel on this stream (uni-hit scans have no feedback)
-        bool const redo = prm->multi_hits != 0 || c->xt_explicit; // explicit transitions may carry E->B feedback
+        // (explicit transitions may carry E->B feedback; flagged profiles leave the kernel through the lists too)
+        bool const redo = prm->multi_hits != 0 || c->xt_explicit || (dcp_qlane_exact_e_by_redo() && c->any_exact_e);
         unsigned redo_grid[kNumClasses] = {0};
         if (redo)
         {

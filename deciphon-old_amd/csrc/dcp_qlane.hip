@@ -54,6 +54,35 @@ constexpr unsigned kPlanes = kRecomputeB ? 3u : 4u; // scratch planes per block:
 #endif
 constexpr unsigned kWMask = (DCP_QLANE_DIAG & 1) ? 0u : 1023u;
 
+// Round-3 trims of the row's bookkeeping instructions.  The row is VALU-bound -- 817 SIMD cycles per
+// wavefront-row against 773 for its arithmetic alone (profiles/r03/row_valu.txt) -- so what is left is
+// instruction count:
+//   WPLANE  the sequence window of every row comes ready-made ((w << 4) | image base) from a per-block
+//           plane [row][lane] built once per scan, instead of being shifted together from packed words in
+//           every tile's sweep: -5 VALU per row; 4 bytes per row and lane from L2 (all blocks share the
+//           few query blocks of a step) instead of a quarter byte
+//   IN16    the insert / background table has 16-byte rows like the match images, so its gathers reuse the
+//           match table's byte offsets: -5 v_lshrrev per row, +10.9 KB of LDS per table.  Single-stage
+//           kernel only: the two-stage kernel's 160 KiB are spoken for -- two images, the table and a
+//           16-row ring -- and the ring cannot shrink: with the hand-shake once per five-row group the
+//           producer may start a group only when the consumer has taken row p + 4 - kRD (+ hysteresis),
+//           the consumer only when row c + 6 (+ hysteresis) is written, so fewer than 12 rows can leave
+//           both waiting (an 8-row ring did: a hung parity test, round 3).
+//   EM      E(j) is the maximum over the MATCH states only: with MD, DD <= 0 -- every model whose
+//           transitions are log-probabilities -- D_k <= max_{i<k} M_i, so the delete states never decide
+//           it (exactly: an add of a non-positive number never rounds up); -4 v_max3 per row.  A profile
+//           with a positive MD or DD is flagged at upload and its pairs go to the row sweep (redo lists).
+#ifndef DCP_QL_WPLANE
+#define DCP_QL_WPLANE 1
+#endif
+#ifndef DCP_QL_IN16
+#define DCP_QL_IN16 1
+#endif
+#ifndef DCP_QL_EM
+#define DCP_QL_EM 1
+#endif
+constexpr bool kWPlane = DCP_QL_WPLANE != 0, kIn16 = DCP_QL_IN16 != 0, kEM = DCP_QL_EM != 0;
+
 // Read-only tables are accessed through the constant address space: the data
 // never changes during the kernel, and loads at wave-uniform addresses then
 // become scalar (SMEM) loads instead of per-lane VMEM loads -- the compiler
@@ -166,7 +195,7 @@ enum
     IO_HBM = 1,
     IO_LDS = 2
 };
-constexpr unsigned kRD = 16;      // rows of the LDS ring (power of two)
+constexpr unsigned kRD = 16;      // rows of the LDS ring (power of two; at least 12: see IN16 above)
 constexpr unsigned kRLanes = 256; // lanes (queries) per stage
 constexpr unsigned kRingPlaneBytes = kRD * kRLanes * 4u;
 // Tuning knobs of the ring hand-shake, measured on the C3 step (profiles/r02/qlane2_tuning.txt; ms of the
@@ -225,6 +254,8 @@ constexpr unsigned kL2Tab1 = 65536u;                   // image of the odd tile
 constexpr unsigned kL2Ring = 7u * kRingPlaneBytes;     // 114 688 .. 163 840
 constexpr unsigned kL2Bytes = kL2Ring + 3u * kRingPlaneBytes;
 static_assert(kL2Task + 16u <= kL2Tab1 && kL2Tab1 + kL2TabIN <= kL2Ring && kL2Bytes == 160u * 1024u, "LDS layout");
+static_assert((kL2Ring & (kRingPlaneBytes - 1u)) == 0u, "ring slots are addressed by OR");
+static_assert(kRD >= 12u, "a shorter ring can deadlock the two stages (five-row hand-shake groups)");
 
 // The ring's flags are relaxed workgroup-scope atomics and its data plain LDS accesses: `volatile` would
 // make the backend's memory legalizer put s_waitcnt vmcnt(0) lgkmcnt(0) behind every access, which
@@ -232,6 +263,14 @@ static_assert(kL2Task + 16u <= kL2Tab1 && kL2Tab1 + kL2TabIN <= kL2Ring && kL2By
 // What is needed is ORDER only, and LDS gives it in hardware (one wavefront's operations execute in
 // order); the compiler is held to it by empty asm statements that clobber "memory".
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+// The same fence, leaving a comment in the emitted ISA: tests/test_isa_order.py assembles this file and checks
+// that between the marks the LDS operations of the ring hand-off come out in program order -- data stores,
+// THEN the flag store; flag load, THEN the data loads; data loads, THEN the "taken" flag -- which is what
+// the protocol relies on.  HARDWARE ASSUMPTION: the LDS executes one wavefront's DS
+// operations in issue order, so a partner that observes the flag also observes the data written before it.
+// (The HIP memory model gives no such edge for relaxed atomics; release / acquire atomics would, at the price
+// of an s_waitcnt lgkmcnt(0) that drains the row's gathers in flight.)
+#define DCP_ISA_MARK(name) asm volatile("; " name ::: "memory")
 __device__ __forceinline__ unsigned flag_load(lds_uint *flag)
 {
     return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -249,7 +288,7 @@ __device__ __forceinline__ unsigned ring_wait(LdsLink const &lk, unsigned need)
         __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
         v = __builtin_amdgcn_readfirstlane(flag_load(flag));
     }
-    compiler_fence(); // acquire: the ring reads that follow stay behind the flag read
+    DCP_ISA_MARK("DCP_RING_ACQUIRED"); // acquire: the ring reads that follow stay behind the flag read
     return v;
 }
 // boundary values of the row whose scratch-plane byte offset is `rowoff`
@@ -319,12 +358,18 @@ template <unsigned BASE> struct GatherMasks
 };
 template <unsigned BASE> __device__ __forceinline__ GatherOff gather_off(unsigned w, GatherMasks<BASE> const &gm)
 {
-    unsigned const w16 = (w << 4) | gm.base;
+    // kWPlane: the plane already holds (w << 4) | BASE
+    unsigned const w16 = kWPlane ? ((DCP_QLANE_DIAG & 1) ? (w & 0xffff0000u) : w) : ((w << 4) | gm.base);
     GatherOff g;
 #pragma unroll
     for (int l = 0; l < 4; ++l)
         g.a[l] = w16 & gm.m[l];
-    g.a[4] = w16; // the window is 10 bits: all of it
+    // the window is 10 bits: all of it.  With window planes w16 IS the loaded value: the offset must live in
+    // a register of its own, or the slot cannot be refilled in place while this row's gathers still need the
+    // old value -- the allocator then refills another register and copies it into place at the loop's back
+    // edge, and a copy of a value loaded a moment ago is a s_waitcnt vmcnt(0) (one v_mov: 2.3 cycles).
+    if constexpr (kWPlane && !(DCP_QLANE_DIAG & 1)) asm volatile("v_mov_b32 %0, %1" : "=v"(g.a[4]) : "v"(w16));
+    else g.a[4] = w16;
     return g;
 }
 template <int GROUP> __device__ __forceinline__ float4 gather_match(float const *tabM, GatherOff const &g, int l)
@@ -334,7 +379,7 @@ template <int GROUP> __device__ __forceinline__ float4 gather_match(float const 
                                              (g.a[l] + (first[l] + (unsigned)GROUP * NC) * 16u));
 }
 
-template <int G, bool FIRST, bool LAST>
+template <int G, bool FIRST, bool LAST, bool IN16>
 __device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float2 const *tabIN, GatherOff const &g)
 {
     constexpr unsigned first[5] = {0u, 4u, 20u, 84u, 340u};
@@ -343,8 +388,9 @@ __device__ __forceinline__ void ql_fetch(RowIn &in, float const *tabM, float2 co
     {
         in.e0[l] = gather_match<0>(tabM, g, l);
         // insert and background emissions of a word sit side by side: one ds_read_b64
-        float2 const v = *reinterpret_cast<float2 const *>(reinterpret_cast<char const *>(tabIN) +
-                                                           ((g.a[l] >> 1) + first[l] * 8u));
+        // IN16: the same byte offset as the match gather (the image base in it is the table's base too)
+        float2 const v = *reinterpret_cast<float2 const *>(
+            reinterpret_cast<char const *>(tabIN) + (IN16 ? g.a[l] + first[l] * 16u : (g.a[l] >> 1) + first[l] * 8u));
         in.eI[l] = v.x;
         in.eN[l] = v.y;
     }
@@ -358,7 +404,8 @@ template <int R> __device__ __forceinline__ float comp(float4 const &v)
 // One row of one tile for this lane's query.  PH = j % 5 (compile time).
 // `in` holds this row's prefetched inputs and is refilled for row j+1 (window
 // wn) as soon as group 0 has consumed it.
-template <int G, bool FIRST, bool LAST, int PH, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u>
+template <int G, bool FIRST, bool LAST, int PH, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u,
+          bool IN16 = kIn16>
 __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, float const *tabM,
                                        float2 const *tabIN, GatherOff &go,
                                        unsigned wn, RowIn &in, Ring &ring, float *pB, float *pXm,
@@ -432,6 +479,7 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     }
 
     float pm = ni, pi = ni, pd = ni; // node k-1 of this row
+    float m_even = ni;               // kEM: M of the even node, folded into E together with the odd one's
     auto node = [&](int k, float e0, float e1, float e2, float e3, float e4) {
         float const m = mx5(s.P[s1][k] + e0, s.P[s2][k] + e1, s.P[s3][k] + e2, s.P[s4][k] + e3,
                             s.P[s5][k] + e4);
@@ -448,7 +496,13 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
             d = fmaxf(pm + tr.md[k], pd + tr.dd[k]);
             pin = mx3(pm + tr.mm[k], pi + tr.im[k], pd + tr.dm[k]);
         }
-        E = mx3(E, m, d);
+        if constexpr (kEM)
+        {
+            // E(j) = max over the match states: D_k <= max_{i<k} M_i when MD, DD <= 0 (checked at upload)
+            if (k & 1) E = mx3(E, m_even, m);
+            else m_even = m;
+        }
+        else E = mx3(E, m, d);
         s.P[PH][k] = fmaxf(Bj + tr.ent[k], pin);
         s.Q[PH][k] = fmaxf(m + tr.mi[k], iv + tr.ii[k]);
         pm = m, pi = iv, pd = d;
@@ -482,19 +536,20 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
     // group 1's gathers (issued at the top of the row) are the only LDS reads in flight: one wait
     __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); // lgkmcnt(0)
     go = gather_off<TBASE>(wn, gm);
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
+    ql_fetch<G, FIRST, LAST, IN16>(in, tabM, tabIN, go);
     if constexpr (!FIRST && IN == IO_LDS)
     {
         // row j+1's boundary from the LDS ring (the sweep loop made sure the producer has written it);
         // then tell the producer the slot is taken -- LDS runs these in order
         constexpr int sl = (PH + 1) % 5;
-        compiler_fence(); // not above the availability check of this row
+        DCP_ISA_MARK("DCP_RING_TAKE"); // not above the availability check of this row
         unsigned const nxt = off + kRLanes * 4u; // row j+1
         ring.Xm[sl] = ring_ld(lk, nxt, 0);
         ring.Xd[sl] = ring_ld(lk, nxt, 1);
         ring.Em[sl] = ring_ld(lk, nxt, 2);
-        compiler_fence();
+        DCP_ISA_MARK("DCP_RING_TAKEN");
         ring_publish(lk, off, jrow + 1u);
+        DCP_ISA_MARK("DCP_RING_TAKE_END");
     }
 
 #pragma unroll
@@ -520,12 +575,13 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
         float const oXd = fmaxf(pm + tr.md[KT], pd + tr.dd[KT]);
         if constexpr (OUT == IO_LDS)
         {
-            compiler_fence(); // not above the free-slot check of this row
+            DCP_ISA_MARK("DCP_RING_DATA"); // not above the free-slot check of this row
             ring_st(lk, off, 0, oXm);
             ring_st(lk, off, 1, oXd);
             ring_st(lk, off, 2, E);
-            compiler_fence();
+            DCP_ISA_MARK("DCP_RING_FLAG");
             ring_publish(lk, off, jrow); // after the data: LDS keeps this wavefront's order
+            DCP_ISA_MARK("DCP_RING_DATA_END");
         }
         else
         {
@@ -558,7 +614,8 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 
 // Sweep one tile over rows 1..L of this lane's query.  Scratch planes are
 // addressed as (wave-uniform plane base) + (32-bit lane/row offset).
-template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u>
+template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u,
+          bool IN16 = kIn16>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
                                          uint32_t const *__restrict__ wordsT,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
@@ -620,10 +677,32 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
     // phi copy and costs a vmcnt(0) drain each time.)
     unsigned j = 1;
-    unsigned const w0 = wordsT[tid];
-    unsigned wq[5] = {w0, w0, w0, w0, w0}; // rows 1..5 take bases 2..6: all in word 0
-    unsigned w = w0 & 3u & wmask;
-    unsigned wn = ((w << 2) | ((w0 >> 2) & 3u)) & wmask;
+    unsigned wq[5], w, wn;
+    if constexpr (kWPlane)
+    {
+        // wordsT = this block's window plane [row][lane]: row r holds ((window of row r) << 4) | image base
+        // (row 0 unused, 8 rows past the longest member are there to be prefetched).  wq[r % 5] = row r's
+        // window, r = 2..6: a slot is used by exactly one phase (row j reads slot (j + 1) % 5 for its
+        // gather prefetch and then refills it for row j + 6), so no value ever moves between registers.
+        w = wordsT[NT + tid];
+#pragma unroll
+        for (int r = 2; r < 7; ++r)
+            wq[r % 5] = wordsT[r * NT + tid];
+        wn = 0u;
+        // all seven are waited for here, once per sweep: a load still pending on the way into the row loop
+        // would make the compiler's (static) wait for its first use drain the loop's own prefetches every
+        // fifth row -- the back-edge path has 16+ younger operations behind such a value, the entry path none
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    }
+    else
+    {
+        unsigned const w0 = wordsT[tid];
+#pragma unroll
+        for (int h = 0; h < 5; ++h)
+            wq[h] = w0; // rows 1..5 take bases 2..6: all in word 0
+        w = w0 & 3u & wmask;
+        wn = ((w << 2) | ((w0 >> 2) & 3u)) & wmask;
+    }
     RowIn in;
     Ring ring;
 #pragma unroll
@@ -634,18 +713,20 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     }
     GatherMasks<TBASE> const gm;
     GatherOff go = gather_off<TBASE>(w, gm);
-    ql_fetch<G, FIRST, LAST>(in, tabM, tabIN, go);
+    ql_fetch<G, FIRST, LAST, IN16>(in, tabM, tabIN, go);
     if constexpr (!FIRST && IN == IO_LDS)
     {
         // start kRingSkew rows behind the producer, then row 1 -> slot 1
         static_assert(NT == (int)kRLanes, "the ring's row stride is the scratch planes' row stride");
         unsigned const need0 = Lwave < kRingSkew ? Lwave : kRingSkew;
         lk.seen = ring_wait(lk, need0);
+        DCP_ISA_MARK("DCP_RING_TAKE");
         ring.Xm[1] = ring_ld(lk, off, 0); // row 1
         ring.Xd[1] = ring_ld(lk, off, 1);
         ring.Em[1] = ring_ld(lk, off, 2);
-        compiler_fence();
+        DCP_ISA_MARK("DCP_RING_TAKEN");
         ring_publish(lk, off, 1u);
+        DCP_ISA_MARK("DCP_RING_TAKE_END");
     }
     else
     {
@@ -666,9 +747,19 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     {                                                                                      \
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
-        ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT, TBASE>(s, tr, tabM, tabIN, go, wn, in, ring, pB, pXm, \
+        ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT, TBASE, IN16>(s, tr, tabM, tabIN, go,              \
+                                   kWPlane ? wq[(PH + 1) % 5] : wn, in, ring, pB, pXm,     \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o, lk, j, gm QL_DIAG4_ARGS);                     \
+        if constexpr (kWPlane)                                                             \
+        {   /* the slot just read (row j+1's window, loaded five rows ago) takes row j+6's: one coalesced */ \
+            /* load, SGPR row pointer + the lane's byte offset re-derived from `off`, as below            */ \
+            gu32_ptr wrow = (gu32_ptr)wordsT + (pos + 5u) * (unsigned)NT;                     \
+            asm volatile("" : "+s"(wrow));                                                   \
+            wq[(PH + 1) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & ((unsigned)NT * 4u - 1u))); \
+        }                                                                                    \
+        else                                                                                 \
+        {                                                                                    \
         wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
         {   /* row j + kWD.  The row pointer is wave-uniform: pinning it to SGPRs makes the load     */ \
             /* "SGPR base + lane offset"; left alone, the compiler hoists wordsT + lane into a 64-bit */ \
@@ -678,6 +769,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
             /* lane offset re-derived from `off` each row: a loop-invariant one would be widened */ \
             /* to 64 bits outside the loop and the SGPR-base addressing mode would be lost       */ \
             wq[(PH + kWD) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & ((unsigned)NT * 4u - 1u))); \
+        }                                                                                        \
         }                                                                                        \
         off += rowstep * 4u;                                                                     \
         QL_DIAG4_STEP                                                                            \
@@ -716,6 +808,18 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
 #undef QL_ROW
 }
 
+// [code] = {insert, background} emissions of the task's profile, 8-byte rows or (IN16) 16-byte rows
+template <bool IN16>
+__device__ __forceinline__ void fill_tab_in(float *tab, float const *__restrict__ gi, float const *__restrict__ gn, unsigned t,
+                                            unsigned nthreads)
+{
+    for (unsigned i = t; i < (unsigned)NC; i += nthreads)
+    {
+        if constexpr (IN16) *reinterpret_cast<float4 *>(tab + 4u * i) = float4{gi[i], gn[i], 0.0f, 0.0f};
+        else *reinterpret_cast<float2 *>(tab + 2u * i) = float2{gi[i], gn[i]};
+    }
+}
+
 __device__ __forceinline__ unsigned wave_umax(unsigned v)
 {
 #pragma unroll
@@ -734,7 +838,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 {
     constexpr int KT = 4 * G;
     constexpr int TAB_FLOATS = G * NC * 4;
-    __shared__ __attribute__((aligned(16))) float lds[TAB_FLOATS + 2 * NC];
+    __shared__ __attribute__((aligned(16))) float lds[TAB_FLOATS + (kIn16 ? 4 : 2) * NC];
     __shared__ unsigned s_task;
     float *tabM = lds;
     float2 *tabIN = reinterpret_cast<float2 *>(lds + TAB_FLOATS); // [code] = {insert, background}
@@ -775,8 +879,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
         {
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
-            for (unsigned i = tid; i < (unsigned)NC; i += (unsigned)NT)
-                tabIN[i] = float2{gi[i], gn[i]};
+            fill_tab_in<kIn16>(lds + TAB_FLOATS, gi, gn, tid, (unsigned)NT);
         }
 
         SweepOut o{ninf(), ninf(), ninf()};
@@ -810,9 +913,9 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 #undef QL_SWEEP
         }
 
-        if (has && dirty)
+        if (has && (dirty || (kEM && pm.needs_exact_e)))
         {
-            // B0 was not the solution for this pair: the row-sweep kernel scores it
+            // B0 was not the solution for this pair (or its profile has a positive MD / DD): the row-sweep kernel scores it
             unsigned const cls = pm.cls;
             unsigned const i = atomicAdd(a.redo_n + cls, 1u);
             if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
@@ -867,7 +970,6 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
 #endif
     float *const rnull = lds + kL2Null / 4u;
     unsigned *const s_task_p = reinterpret_cast<unsigned *>(lds + kL2Task / 4u);
-    float2 *const tabIN = reinterpret_cast<float2 *>(lds + kL2TabIN / 4u); // [code] = {insert, background}
     float *const tabM = lds + (stage ? kL2Tab1 / 4u : 0u);
     size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane;
@@ -911,8 +1013,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
         {
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
-            for (unsigned i = threadIdx.x; i < (unsigned)NC; i += 512u)
-                tabIN[i] = float2{gi[i], gn[i]};
+            fill_tab_in<false>(lds + kL2TabIN / 4u, gi, gn, threadIdx.x, 512u);
         }
 
         SweepOut o{ninf(), ninf(), ninf()};
@@ -940,9 +1041,10 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
 #if DCP_QLANE_DIAG & 4
 #error "the two-stage kernel has no DIAG=4 build"
 #endif
+    /* tabIN as seen from the gather offsets: its 8-byte rows are reached from (window >> 1), i.e. from half the image base */
 #define QL2_SWEEP(F, L_, IN_, OUT_, TB_)                                                                  \
-    ql_sweep<G, F, L_, NT, D, IN_, OUT_, TB_>(tt, lds, reinterpret_cast<float2 const *>(lds + (kL2TabIN - TB_ / 2u) / 4u), \
-                                              wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
+    ql_sweep<G, F, L_, NT, D, IN_, OUT_, TB_, false>(tt, lds, reinterpret_cast<float2 const *>(lds + (kL2TabIN - TB_ / 2u) / 4u), \
+                                              (kWPlane && TB_ != 0u) ? wordsT + a.wplane1 : wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
             if (stage == 0u)
             {
                 if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM, 0u);
@@ -962,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
 
         unsigned const final_stage = (T - 1u) & 1u; // the stage that swept the last tile
         if (stage != final_stage) continue;
-        if (has && dirty)
+        if (has && (dirty || (kEM && pm.needs_exact_e)))
         {
             unsigned const cls = pm.cls;
             unsigned const i = atomicAdd(a.redo_n + cls, 1u);
@@ -1058,7 +1160,7 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
 #define QLW_SWEEP(F, L_)                                                                                  \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{})
+    ql_sweep<G, F, L_, NT, D, IO_HBM, IO_HBM, 0u, false>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{})
             if (first && last) QLW_SWEEP(true, true);
             else if (first) QLW_SWEEP(true, false);
             else if (last) QLW_SWEEP(false, true);
@@ -1066,7 +1168,7 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
 #undef QLW_SWEEP
             compiler_fence(); // ... and the next image's stores behind this sweep's gathers
         }
-        if (has && dirty)
+        if (has && (dirty || (kEM && pm.needs_exact_e)))
         {
             unsigned const cls = pm.cls;
             unsigned const i = atomicAdd(a.redo_n + cls, 1u);
@@ -1090,7 +1192,10 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
     }
 }
 
-// words_t[wt_off[qb] + w * NT + t] = word w of the query in lane t of block qb (0 past its end)
+// kWPlane: words_t[wt_off[qb] + r * NT + t] = (window of row r of the query in lane t of block qb) << 4, the window
+// being the base-4 value of the last five bases up to position r (zeros before the start, anything valid
+// past the end); a second plane `wplane1` words further on carries the same values | 64 KiB, the LDS base
+// of the two-stage kernel's second image.  Otherwise: word w of the query (0 past its end).
 template <int NT>
 __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
 {
@@ -1098,12 +1203,31 @@ __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
     unsigned const qi = qb * (unsigned)NT + tid;
     bool const has = qi < a.nseqs;
     unsigned const q = has ? a.qorder[qi] : 0u;
-    unsigned const nw = has ? a.seq_len[q] / 16u + 3u : 0u; // words the upload packed for q
     uint32_t const *__restrict__ src = a.seq_words + a.seq_woff[q];
     unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) / (unsigned)NT;
     uint32_t *dst = a.words_t + a.wt_off[qb];
-    for (unsigned w = 0; w < rows; ++w)
-        dst[w * (unsigned)NT + tid] = w < nw ? src[w] : 0u;
+    if constexpr (kWPlane)
+    {
+        unsigned const len = has ? a.seq_len[q] : 0u;
+        unsigned w = 0, word = 0;
+        for (unsigned r = 0; r < rows; ++r)
+        {
+            if (r >= 1u)
+            {
+                unsigned const pos = r - 1u; // row r ends with base r - 1
+                if ((pos & 15u) == 0u) word = pos < len ? src[pos >> 4] : 0u;
+                w = ((w << 2) | ((pos < len ? word >> ((pos & 15u) * 2u) : 0u) & 3u)) & 1023u;
+            }
+            dst[r * (unsigned)NT + tid] = w << 4;
+            if (a.wplane1) dst[a.wplane1 + r * (unsigned)NT + tid] = (w << 4) | kL2Tab1;
+        }
+    }
+    else
+    {
+        unsigned const nw = has ? a.seq_len[q] / 16u + 3u : 0u; // words the upload packed for q
+        for (unsigned w = 0; w < rows; ++w)
+            dst[w * (unsigned)NT + tid] = w < nw ? src[w] : 0u;
+    }
 }
 
 template <int G, int NT, int D>
@@ -1126,6 +1250,10 @@ extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
+// rows of a block's sequence plane for a longest member of `lmax` bases: window rows 0..lmax + 8, or packed words
+extern "C" unsigned dcp_qlane_plane_rows(unsigned lmax) { return kWPlane ? lmax + 9u : lmax / 16u + 3u; }
+extern "C" unsigned dcp_qlane_window_planes(void) { return kWPlane ? 1u : 0u; }
+extern "C" unsigned dcp_qlane_exact_e_by_redo(void) { return kEM ? 1u : 0u; }
 
 extern "C" int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream)
 {

