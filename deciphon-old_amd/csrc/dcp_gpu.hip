@@ -109,6 +109,11 @@ struct dcp_gpu_ctx
     DevBuf<uint32_t> d_qorder;
     DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block sequence planes (row windows, or packed words)
     uint32_t wplane1 = 0;                 // word offset of the second window plane (two-stage kernel), 0 = none
+    // the length-sorted query order and the plane offsets travel through pinned host memory: the copies are
+    // truly asynchronous and dcp_gpu_scan_range returns without waiting for the stream
+    uint32_t *h_qstage = nullptr;
+    size_t h_qstage_n = 0;
+    hipEvent_t ev_qstage = nullptr;       // recorded behind the copies: the buffer may be rewritten after it
     unsigned qorder_planes = 0;           // planes the cached layout holds
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
@@ -239,6 +244,8 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev_qstage) (void)hipEventDestroy(c->ev_qstage);
+    if (c->h_qstage) (void)hipHostFree(c->h_qstage);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (int k = 0; k <= kNumClasses; ++k)
@@ -947,22 +954,33 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         unsigned const nplanes = dcp_qlane_window_planes() ? (two_stage ? 2u : 1u) : 1u;
         if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt || c->qorder_planes != nplanes)
         {
-            std::vector<uint32_t> ord(nq);
+            unsigned const NTq = ql_nt;
+            unsigned const nqb = (nq + NTq - 1u) / NTq;
+            // pinned staging: [nq] order, [nqb + 1] plane offsets
+            size_t const need_stage = (size_t)nq + nqb + 1u;
+            if (!c->ev_qstage) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_qstage, hipEventDisableTiming));
+            else HIP_TRY(c, hipEventSynchronize(c->ev_qstage)); // the previous layout's copies have left the buffer
+            if (c->h_qstage_n < need_stage)
+            {
+                if (c->h_qstage) (void)hipHostFree(c->h_qstage);
+                c->h_qstage = nullptr, c->h_qstage_n = 0;
+                HIP_TRY(c, hipHostMalloc((void **)&c->h_qstage, need_stage * sizeof(uint32_t), hipHostMallocDefault));
+                c->h_qstage_n = need_stage;
+            }
+            uint32_t *const ord = c->h_qstage, *const wt_off = c->h_qstage + nq;
             for (unsigned i = 0; i < nq; ++i)
                 ord[i] = i;
-            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+            std::stable_sort(ord, ord + nq, [&](uint32_t x, uint32_t y) {
                 return c->seq_len[q_begin + x] < c->seq_len[q_begin + y];
             });
             unsigned lmax = 0;
             for (unsigned q = q_begin; q < q_end; ++q)
                 lmax = std::max(lmax, c->seq_len[q]);
             if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
-            HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord.data(), nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord, nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             // per block of NT queries: the rows of its sequence plane (dcp_qlane_plane_rows of its longest member)
-            unsigned const NTq = ql_nt;
-            unsigned const nqb = (nq + NTq - 1u) / NTq;
-            std::vector<uint32_t> wt_off(nqb + 1u, 0u);
             uint64_t tot = 0;
+            wt_off[0] = 0u;
             for (unsigned b = 0; b < nqb; ++b)
             {
                 unsigned const lastq = std::min(nq, (b + 1u) * NTq) - 1u; // ascending lengths
@@ -973,7 +991,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             if (c->d_wt_off.n < nqb + 1u) HIP_TRY(c, c->d_wt_off.alloc(nqb + 1u));
             if (c->d_words_t.n < tot * nplanes) HIP_TRY(c, c->d_words_t.alloc((size_t)(tot * nplanes)));
             c->wplane1 = nplanes > 1u ? (uint32_t)tot : 0u;
-            HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off.data(), (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off, (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_qstage, c->stream));
             dcp_qlane_args ta{};
             ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
             ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
@@ -981,7 +1000,6 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             ta.wplane1 = c->wplane1;
             if (dcp_launch_qlane_transpose(&ta, NTq, c->stream)) return c->fail(DCP_EFAIL, "no kernel for %u-query blocks", NTq);
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipStreamSynchronize(c->stream)); // ord / wt_off are stack-local
             c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax, c->qorder_nt = NTq;
             c->qorder_planes = nplanes;
         }
