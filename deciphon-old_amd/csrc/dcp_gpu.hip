@@ -108,13 +108,11 @@ struct dcp_gpu_ctx
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
     DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block sequence planes (row windows, or packed words)
-    uint32_t wplane1 = 0;                 // word offset of the second window plane (two-stage kernel), 0 = none
     // the length-sorted query order and the plane offsets travel through pinned host memory: the copies are
     // truly asynchronous and dcp_gpu_scan_range returns without waiting for the stream
     uint32_t *h_qstage = nullptr;
     size_t h_qstage_n = 0;
     hipEvent_t ev_qstage = nullptr;       // recorded behind the copies: the buffer may be rewritten after it
-    unsigned qorder_planes = 0;           // planes the cached layout holds
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
@@ -951,8 +949,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     if (kernel == 2)
     {
         // queries sorted by length so that the lanes of a block finish together
-        unsigned const nplanes = dcp_qlane_window_planes() ? (two_stage ? 2u : 1u) : 1u;
-        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt || c->qorder_planes != nplanes)
+        if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt)
         {
             unsigned const NTq = ql_nt;
             unsigned const nqb = (nq + NTq - 1u) / NTq;
@@ -985,23 +982,20 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             {
                 unsigned const lastq = std::min(nq, (b + 1u) * NTq) - 1u; // ascending lengths
                 tot += (uint64_t)dcp_qlane_plane_rows(c->seq_len[q_begin + ord[lastq]]) * NTq;
-                if (tot * nplanes > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
+                if (tot > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
                 wt_off[b + 1u] = (uint32_t)tot;
             }
             if (c->d_wt_off.n < nqb + 1u) HIP_TRY(c, c->d_wt_off.alloc(nqb + 1u));
-            if (c->d_words_t.n < tot * nplanes) HIP_TRY(c, c->d_words_t.alloc((size_t)(tot * nplanes)));
-            c->wplane1 = nplanes > 1u ? (uint32_t)tot : 0u;
+            if (c->d_words_t.n < tot) HIP_TRY(c, c->d_words_t.alloc((size_t)tot));
             HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off, (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev_qstage, c->stream));
             dcp_qlane_args ta{};
             ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
             ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
             ta.nseqs = nq, ta.nqblocks = nqb;
-            ta.wplane1 = c->wplane1;
             if (dcp_launch_qlane_transpose(&ta, NTq, c->stream)) return c->fail(DCP_EFAIL, "no kernel for %u-query blocks", NTq);
             HIP_TRY(c, hipGetLastError());
             c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax, c->qorder_nt = NTq;
-            c->qorder_planes = nplanes;
         }
         if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
     }
@@ -1024,7 +1018,6 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.qorder = c->d_qorder.p;
         qa.words_t = c->d_words_t.p;
         qa.wt_off = c->d_wt_off.p;
-        qa.wplane1 = c->wplane1;
         qa.task_counter = c->d_task_counter.p;
         qa.out_null = a.out_null;
         qa.out_alt = a.out_alt;

@@ -123,7 +123,6 @@ struct dcp_qlane_args
     // words_t[wt_off[qb] + w * (queries per block) + t] -- one coalesced load per row
     uint32_t *words_t;
     uint32_t const *wt_off;   // [nqblocks + 1]
-    uint32_t wplane1;         // window planes: word offset of the second plane (values | 64 KiB), 0 = none
     float *scratch;           // [nblocks][3 (or 4) planes][lmax + 8][queries per block]
     unsigned *task_counter;
     // redo lists, one per row-sweep size class: pairs whose B0(j) = N(j) + NB was beaten by the
@@ -176,7 +175,7 @@ unsigned dcp_qlane_tile_nodes(void);
 unsigned dcp_qlane_scratch_planes(void);
 unsigned dcp_qlane_diag_build(void); // != 0: a -DDCP_QLANE_DIAG timing build (wrong results)
 unsigned dcp_qlane_plane_rows(unsigned lmax); // rows of a query block's sequence plane
-unsigned dcp_qlane_window_planes(void);       // != 0: the plane holds per-row windows (two copies for the two-stage kernel)
+unsigned dcp_qlane_window_planes(void);       // != 0: the plane holds per-row windows (uint16) instead of packed words
 unsigned dcp_qlane_exact_e_by_redo(void);     // != 0: profiles with a positive MD / DD must go through the redo lists
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@
 #include "dcp_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace
 {
@@ -57,10 +58,10 @@ constexpr unsigned kWMask = (DCP_QLANE_DIAG & 1) ? 0u : 1023u;
 // Round-3 trims of the row's bookkeeping instructions.  The row is VALU-bound -- 817 SIMD cycles per
 // wavefront-row against 773 for its arithmetic alone (profiles/r03/row_valu.txt) -- so what is left is
 // instruction count:
-//   WPLANE  the sequence window of every row comes ready-made ((w << 4) | image base) from a per-block
-//           plane [row][lane] built once per scan, instead of being shifted together from packed words in
-//           every tile's sweep: -5 VALU per row; 4 bytes per row and lane from L2 (all blocks share the
-//           few query blocks of a step) instead of a quarter byte
+//   WPLANE  the sequence window of every row comes ready-made (w << 4, 16 bits) from a per-block plane
+//           [row][lane] built once per scan, instead of being shifted together from packed words in every
+//           tile's sweep: -5 VALU per row (stage 1 of the two-stage kernel: -4, it ORs its image base in);
+//           2 bytes per row and lane instead of a quarter byte (+0.9 TB of the 6.3 TB a C3 launch moves)
 //   IN16    the insert / background table has 16-byte rows like the match images, so its gathers reuse the
 //           match table's byte offsets: -5 v_lshrrev per row, +10.9 KB of LDS per table.  Single-stage
 //           kernel only: the two-stage kernel's 160 KiB are spoken for -- two images, the table and a
@@ -173,6 +174,7 @@ __device__ __forceinline__ float ld_off(float const *base, unsigned boff)
     return *reinterpret_cast<float const *>(reinterpret_cast<char const *>(base) + boff);
 }
 typedef uint32_t const __attribute__((address_space(1))) *gu32_ptr; // explicitly global: survives an asm pin
+typedef uint16_t const __attribute__((address_space(1))) *gu16_ptr;
 typedef char const __attribute__((address_space(1))) *gchar_ptr;
 __device__ __forceinline__ void st_off(float *base, unsigned boff, float v)
 {
@@ -358,8 +360,9 @@ template <unsigned BASE> struct GatherMasks
 };
 template <unsigned BASE> __device__ __forceinline__ GatherOff gather_off(unsigned w, GatherMasks<BASE> const &gm)
 {
-    // kWPlane: the plane already holds (w << 4) | BASE
-    unsigned const w16 = kWPlane ? ((DCP_QLANE_DIAG & 1) ? (w & 0xffff0000u) : w) : ((w << 4) | gm.base);
+    // kWPlane: the plane already holds w << 4; the second image's base is ORed in (an opaque SGPR: see GatherMasks)
+    unsigned const wp = (DCP_QLANE_DIAG & 1) ? 0u : w;
+    unsigned const w16 = kWPlane ? (BASE != 0u ? (wp | gm.base) : wp) : ((w << 4) | gm.base);
     GatherOff g;
 #pragma unroll
     for (int l = 0; l < 4; ++l)
@@ -368,7 +371,7 @@ template <unsigned BASE> __device__ __forceinline__ GatherOff gather_off(unsigne
     // a register of its own, or the slot cannot be refilled in place while this row's gathers still need the
     // old value -- the allocator then refills another register and copies it into place at the loop's back
     // edge, and a copy of a value loaded a moment ago is a s_waitcnt vmcnt(0) (one v_mov: 2.3 cycles).
-    if constexpr (kWPlane && !(DCP_QLANE_DIAG & 1)) asm volatile("v_mov_b32 %0, %1" : "=v"(g.a[4]) : "v"(w16));
+    if constexpr (kWPlane && BASE == 0u && !(DCP_QLANE_DIAG & 1)) asm volatile("v_mov_b32 %0, %1" : "=v"(g.a[4]) : "v"(w16));
     else g.a[4] = w16;
     return g;
 }
@@ -677,17 +680,22 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
     // phi copy and costs a vmcnt(0) drain each time.)
     unsigned j = 1;
-    unsigned wq[5], w, wn;
+    typedef typename std::conditional<kWPlane, uint16_t, unsigned>::type wq_t;
+    wq_t wq[5];
+    unsigned w, wn;
+    unsigned lane2 = tid * 2u; // byte offset of this lane in a window-plane row
+    (void)lane2;
     if constexpr (kWPlane)
     {
-        // wordsT = this block's window plane [row][lane]: row r holds ((window of row r) << 4) | image base
+        // wordsT = this block's window plane [row][lane] of uint16: row r holds (window of row r) << 4
         // (row 0 unused, 8 rows past the longest member are there to be prefetched).  wq[r % 5] = row r's
         // window, r = 2..6: a slot is used by exactly one phase (row j reads slot (j + 1) % 5 for its
         // gather prefetch and then refills it for row j + 6), so no value ever moves between registers.
-        w = wordsT[NT + tid];
+        gu16_ptr const wpl = (gu16_ptr)wordsT;
+        w = wpl[NT + tid];
 #pragma unroll
         for (int r = 2; r < 7; ++r)
-            wq[r % 5] = wordsT[r * NT + tid];
+            wq[r % 5] = wpl[r * NT + tid];
         wn = 0u;
         // all seven are waited for here, once per sweep: a load still pending on the way into the row loop
         // would make the compiler's (static) wait for its first use drain the loop's own prefetches every
@@ -748,19 +756,23 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
         ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT, TBASE, IN16>(s, tr, tabM, tabIN, go,              \
-                                   kWPlane ? wq[(PH + 1) % 5] : wn, in, ring, pB, pXm,     \
+                                   kWPlane ? (unsigned)wq[(PH + 1) % 5] : wn, in, ring, pB, pXm,     \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
                                    dirty, o, lk, j, gm QL_DIAG4_ARGS);                     \
         if constexpr (kWPlane)                                                             \
         {   /* the slot just read (row j+1's window, loaded five rows ago) takes row j+6's: one coalesced */ \
             /* load, SGPR row pointer + the lane's byte offset re-derived from `off`, as below            */ \
-            gu32_ptr wrow = (gu32_ptr)wordsT + (pos + 5u) * (unsigned)NT;                     \
+            /* wq[] is uint16: the zero-extension then happens where the value is USED (folded into the   */ \
+            /* gather masks); as `unsigned` it is a v_and at the loop's back edge, on a value loaded a      */ \
+            /* moment ago -- s_waitcnt vmcnt(0) in every fifth row                                          */ \
+            gu16_ptr wrow = (gu16_ptr)wordsT + (pos + 5u) * (unsigned)NT;                     \
             asm volatile("" : "+s"(wrow));                                                   \
-            wq[(PH + 1) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & ((unsigned)NT * 4u - 1u))); \
+            asm volatile("" : "+v"(lane2)); /* keeps the 32-bit lane offset next to the load */ \
+            wq[(PH + 1) % 5] = *(gu16_ptr)((gchar_ptr)wrow + lane2);                          \
         }                                                                                    \
         else                                                                                 \
         {                                                                                    \
-        wn = ((wn << 2) | ((wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
+        wn = ((wn << 2) | (((unsigned)wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
         {   /* row j + kWD.  The row pointer is wave-uniform: pinning it to SGPRs makes the load     */ \
             /* "SGPR base + lane offset"; left alone, the compiler hoists wordsT + lane into a 64-bit */ \
             /* VGPR pair and adds the row offset with a 64-bit VALU add every row                     */ \
@@ -1044,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     /* tabIN as seen from the gather offsets: its 8-byte rows are reached from (window >> 1), i.e. from half the image base */
 #define QL2_SWEEP(F, L_, IN_, OUT_, TB_)                                                                  \
     ql_sweep<G, F, L_, NT, D, IN_, OUT_, TB_, false>(tt, lds, reinterpret_cast<float2 const *>(lds + (kL2TabIN - TB_ / 2u) / 4u), \
-                                              (kWPlane && TB_ != 0u) ? wordsT + a.wplane1 : wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
+                                              wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
             if (stage == 0u)
             {
                 if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM, 0u);
@@ -1192,10 +1204,9 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
     }
 }
 
-// kWPlane: words_t[wt_off[qb] + r * NT + t] = (window of row r of the query in lane t of block qb) << 4, the window
-// being the base-4 value of the last five bases up to position r (zeros before the start, anything valid
-// past the end); a second plane `wplane1` words further on carries the same values | 64 KiB, the LDS base
-// of the two-stage kernel's second image.  Otherwise: word w of the query (0 past its end).
+// kWPlane: the block's plane is uint16 [rows][NT] starting at word wt_off[qb] of words_t: entry (r, t) = (window of
+// row r of the query in lane t) << 4, the window being the base-4 value of the last five bases up to position
+// r (zeros before the start, anything valid past the end).  Otherwise: word w of the query (0 past its end).
 template <int NT>
 __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
 {
@@ -1204,7 +1215,8 @@ __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
     bool const has = qi < a.nseqs;
     unsigned const q = has ? a.qorder[qi] : 0u;
     uint32_t const *__restrict__ src = a.seq_words + a.seq_woff[q];
-    unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) / (unsigned)NT;
+    // rows of the block's plane: uint16 entries (two per word) with window planes, else one word per entry
+    unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) * (kWPlane ? 2u : 1u) / (unsigned)NT;
     uint32_t *dst = a.words_t + a.wt_off[qb];
     if constexpr (kWPlane)
     {
@@ -1218,8 +1230,7 @@ __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
                 if ((pos & 15u) == 0u) word = pos < len ? src[pos >> 4] : 0u;
                 w = ((w << 2) | ((pos < len ? word >> ((pos & 15u) * 2u) : 0u) & 3u)) & 1023u;
             }
-            dst[r * (unsigned)NT + tid] = w << 4;
-            if (a.wplane1) dst[a.wplane1 + r * (unsigned)NT + tid] = (w << 4) | kL2Tab1;
+            reinterpret_cast<uint16_t *>(dst)[r * (unsigned)NT + tid] = (uint16_t)(w << 4);
         }
     }
     else
@@ -1251,7 +1262,9 @@ extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
 // rows of a block's sequence plane for a longest member of `lmax` bases: window rows 0..lmax + 8, or packed words
-extern "C" unsigned dcp_qlane_plane_rows(unsigned lmax) { return kWPlane ? lmax + 9u : lmax / 16u + 3u; }
+// 32-bit words per lane of a block's sequence plane for a longest member of `lmax` bases: uint16 window rows
+// 0..lmax + 8 (an even number of rows), or packed words
+extern "C" unsigned dcp_qlane_plane_rows(unsigned lmax) { return kWPlane ? (lmax + 10u) / 2u : lmax / 16u + 3u; }
 extern "C" unsigned dcp_qlane_window_planes(void) { return kWPlane ? 1u : 0u; }
 extern "C" unsigned dcp_qlane_exact_e_by_redo(void) { return kEM ? 1u : 0u; }
 
