@@ -3,8 +3,9 @@
 # judged into profiles/rNN/).  Two parts so that each fits one gpurun call:
 #   gpurun --timeout 1100 -- 'bash profiles/measure_round.sh r02m driver'
 #   gpurun --timeout 1100 -- 'bash profiles/measure_round.sh r02m lines'
+#   gpurun --timeout 1190 -- 'bash profiles/measure_round.sh r03m c5full'
 set -o pipefail
-TAG=${1:?tag}; PART=${2:?driver|lines}
+TAG=${1:?tag}; PART=${2:?driver|lines|c5full}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 line() { # name, bench args...
   local name=$1; shift
@@ -20,14 +21,19 @@ lines)
   line c3_rowsweep_bench --kernel rowsweep --steps 3 --warmup 1 --no-cpu-baseline
   line c3_qlane_single_stage_bench --kernel qlane --steps 3 --warmup 1 --no-cpu-baseline
   line c2_bench --workload c2 --steps 5 --warmup 2 --no-cpu-baseline
-  line c5_bench --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
-  line c5_bench_8192q_4000prof --workload c5 --nprof 4000 --qstep 8192 --steps 2 --warmup 1 --no-cpu-baseline
+  line c5_bench_1000q --workload c5 --qstep 1000 --steps 3 --warmup 1 --no-cpu-baseline --e2e-steps 0
+  line c5_bench_8192q_4000prof --workload c5 --nprof 4000 --qstep 8192 --steps 2 --warmup 1 --no-cpu-baseline --e2e-steps 0
   line c3sizes_dense10_consensus_queries_bench --dense 10 --steps 3 --warmup 1 --no-cpu-baseline
   line c3sizes_dense10_random_queries_bench --dense 10 --dense-random --steps 3 --warmup 1 --no-cpu-baseline
   line c3_planted_bench --planted --steps 3 --warmup 1 --no-cpu-baseline
   DCP_BENCH_FORCE_DIST=1 line c3_bench_c_rccl_gather_1rank --steps 3 --warmup 1 --no-cpu-baseline
   timeout -k 10 400 python3 profiles/latency_probe.py > $OUT/latency_probe.txt 2>&1; grep "^auto" $OUT/latency_probe.txt
   timeout -k 10 300 python3 profiles/smalldb_probe.py > $OUT/smalldb_probe.txt 2>&1; tail -3 $OUT/smalldb_probe.txt
+  ;;
+c5full)
+  # BASELINE configs[4] at full size on one GPU: all 20 000 profiles (M 50-2000) x one step of 8 192 mixed-length
+  # queries (1.9e14 cells: ~2 min per step)
+  LINE_TIMEOUT=1000 line c5_bench_8192q_full_db --workload c5 --qstep 8192 --steps 1 --warmup 1 --no-cpu-baseline --e2e-steps 0
   ;;
 esac
 true
