@@ -23,7 +23,10 @@ struct Stamp
 constexpr int KT = 8;
 
 // VARIANT 0: scalar transition adds (SGPR operand); 1: packed (SGPR pairs); 2: scalar adds with the
-// transitions in VGPRs (what it would cost if there were registers for them)
+// transitions in VGPRs (what it would cost if there were registers for them); 3 / 4: variant 0's operations
+// issued in GROUPS -- all emission adds of 2 (3) or 4 (4) nodes, then their max3s, then their transition adds,
+// then the remaining maxima, a scheduling barrier between the groups -- to see whether long runs of the
+// 2-cycle class pair better across the two wavefronts of a SIMD
 template <int VARIANT> __global__ __launch_bounds__(512, 2) void row_kernel(float *out, float const *trans, int rows, Stamp *st)
 {
     extern __shared__ float lds[];
@@ -86,7 +89,49 @@ template <int VARIANT> __global__ __launch_bounds__(512, 2) void row_kernel(floa
 #define ROW(PH)                                                                                                     \
     {                                                                                                               \
         constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;           \
-        if constexpr (VARIANT != 1)                                                                                 \
+        if constexpr (VARIANT == 3 || VARIANT == 4)                                                                 \
+        {                                                                                                           \
+            constexpr int GN = VARIANT == 3 ? 2 : 4;                                                                \
+            float pm = -1e30f, pi = -1e30f, pd = -1e30f;                                                            \
+            _Pragma("unroll") for (int g = 0; g < KT / GN; ++g)                                                      \
+            {                                                                                                       \
+                float am[GN][5], ai[GN][5], m[GN], iv[GN];                                                          \
+                _Pragma("unroll") for (int n = 0; n < GN; ++n)                                                       \
+                {                                                                                                   \
+                    int const k = g * GN + n;                                                                       \
+                    am[n][0] = P[s1][k] + e[0][k], am[n][1] = P[s2][k] + e[1][k], am[n][2] = P[s3][k] + e[2][k];    \
+                    am[n][3] = P[s4][k] + e[3][k], am[n][4] = P[s5][k] + e[4][k];                                   \
+                    ai[n][0] = Q[s1][k] + eI[0], ai[n][1] = Q[s2][k] + eI[1], ai[n][2] = Q[s3][k] + eI[2];          \
+                    ai[n][3] = Q[s4][k] + eI[3], ai[n][4] = Q[s5][k] + eI[4];                                       \
+                }                                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                _Pragma("unroll") for (int n = 0; n < GN; ++n)                                                       \
+                {                                                                                                   \
+                    m[n] = mx5(am[n][0], am[n][1], am[n][2], am[n][3], am[n][4]);                                   \
+                    iv[n] = mx5(ai[n][0], ai[n][1], ai[n][2], ai[n][3], ai[n][4]);                                  \
+                }                                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                _Pragma("unroll") for (int n = 0; n < GN; ++n)                                                       \
+                {                                                                                                   \
+                    int const k = g * GN + n;                                                                       \
+                    float d, pin;                                                                                   \
+                    if (k == 0) d = Xd, pin = Xm;                                                                   \
+                    else                                                                                            \
+                    {                                                                                               \
+                        d = fmaxf(pm + md[k], pd + dd[k]);                                                          \
+                        pin = mx3(pm + mm[k], pi + im[k], pd + dm[k]);                                              \
+                    }                                                                                               \
+                    E = mx3(E, m[n], d);                                                                            \
+                    P[PH][k] = fmaxf(Bj + ent[k], pin);                                                             \
+                    Q[PH][k] = fmaxf(m[n] + mi[k], iv[n] + ii[k]);                                                  \
+                    pm = m[n], pi = iv[n], pd = d;                                                                  \
+                }                                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+            }                                                                                                       \
+            Xm = mx3(pm + mm[KT], pi + im[KT], pd + dm[KT]);                                                        \
+            Xd = fmaxf(pm + md[KT], pd + dd[KT]);                                                                   \
+        }                                                                                                           \
+        else if constexpr (VARIANT != 1)                                                                            \
         {                                                                                                           \
             float pm = -1e30f, pi = -1e30f, pd = -1e30f;                                                            \
             _Pragma("unroll") for (int k = 0; k < KT; ++k)                                                           \
@@ -223,5 +268,7 @@ int main()
     run("scalar transition adds, SGPR operand", row_kernel<0>);
     run("packed transition adds, SGPR pairs", row_kernel<1>);
     run("scalar transition adds, VGPR operand", row_kernel<2>);
+    run("variant 0 in groups of 2 nodes", row_kernel<3>);
+    run("variant 0 in groups of 4 nodes", row_kernel<4>);
     return 0;
 }
