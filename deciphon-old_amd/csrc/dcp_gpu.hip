@@ -369,6 +369,16 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         m.core_size = c->core_sizes[p];
         m.ldk = ldk;
         m.pidx = p;
+        {
+            // E(j) as the match states' maximum (both kernels) needs MD, DD <= 0: true of every profile whose
+            // transitions are log-probabilities.  Any other profile is flagged: the row sweep then takes the
+            // delete states into E(j), the query-lane kernels hand its pairs to the row sweep (redo lists).
+            float const *t8 = dcp_profile_trans8(profiles[p]);
+            bool pos = false;
+            for (unsigned k = 1; k < m.core_size && !pos; ++k) // edges into node 0 do not exist (-inf below)
+                pos = t8[(size_t)DCP_T_MD * m.core_size + k] > 0.0f || t8[(size_t)DCP_T_DD * m.core_size + k] > 0.0f;
+            m.flags = pos ? DCP_PROF_EXACT_E : 0u;
+        }
         dist_row[i] = (uint32_t)match_rows;
         emis_floats += (uint64_t)DCP_NCODES * ldk;
         trans_floats += 8ull * ldk;
@@ -442,16 +452,8 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         c->class_core[qm.cls] += m.core_size;
         c->sum_tiles += qm.ntiles;
         c->max_tiles = std::max(c->max_tiles, qm.ntiles);
-        {
-            // E(j) as the match states' maximum (dcp_qlane.hip, EM) needs MD, DD <= 0: true of every profile
-            // whose transitions are log-probabilities; any other profile is scored by the row sweep
-            float const *t8 = dcp_profile_trans8(profiles[m.pidx]);
-            bool pos = false;
-            for (unsigned k = 0; k < m.core_size && !pos; ++k)
-                pos = t8[(size_t)DCP_T_MD * m.core_size + k] > 0.0f || t8[(size_t)DCP_T_DD * m.core_size + k] > 0.0f;
-            qm.needs_exact_e = pos ? 1u : 0u;
-            c->any_exact_e = c->any_exact_e || pos;
-        }
+        qm.needs_exact_e = (m.flags & DCP_PROF_EXACT_E) ? 1u : 0u;
+        c->any_exact_e = c->any_exact_e || qm.needs_exact_e != 0u;
         qm.tile_off = tile_floats;
         qm.ttrans_off = (uint32_t)ttrans_floats;
         tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
@@ -1133,10 +1135,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         a.first_prof = first;
         a.nprof = last - first;
         SizeClass const sc = kClasses[k];
-        uint64_t const tpb = dcp_rowsweep_tasks_per_block(sc.W);
-        uint64_t ntasks = (uint64_t)a.nprof * a.nchunks;
-        uint64_t nblocks = (ntasks + tpb - 1) / tpb;
-        nblocks = (nblocks + 7) / 8 * 8;
+        uint64_t const ntasks = (uint64_t)a.nprof * a.nchunks;
+        uint64_t const nblocks = dcp_rowsweep_grid_blocks(sc.W, a.nprof, a.nchunks);
         if (ntasks > 0xffffffffull || nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, ls))
             return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);

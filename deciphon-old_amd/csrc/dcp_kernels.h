@@ -13,7 +13,12 @@ struct dcp_prof_meta
     uint32_t core_size; // M
     uint32_t ldk;       // padded node count = lanes * R of its size class
     uint32_t pidx;      // index in the caller's profile order
+    uint32_t flags;     // DCP_PROF_EXACT_E
+    uint32_t reserved;
 };
+// a finite MD or DD > 0: E(j) is not the maximum of the match states alone (a delete state may exceed every
+// match state before it), so the kernels take the delete states into E(j) for this profile
+#define DCP_PROF_EXACT_E 1u
 
 // a (query, profile) pair the query-lane kernel hands to the row-sweep kernel
 struct dcp_pair
@@ -162,6 +167,8 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
+// blocks of a grid-mode launch (all queries x the profiles of one size class); a multiple of 8
+uint64_t dcp_rowsweep_grid_blocks(int W, unsigned nprof, unsigned nchunks);
 int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream); // nt: 64, 128 or 256 queries per block
 // two-stage variant: 512-thread blocks, one per CU; != 0 if the kernel cannot be configured
 int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream);

@@ -90,9 +90,11 @@ template <bool HAS_FIRST> __device__ __forceinline__ float shr1_add(float x, flo
 __device__ __forceinline__ float wave_max(float v)
 {
     float r;
-    asm("v_mov_b32 %0, %1\n\t"
-        "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    // first step with bound_ctrl:0: a lane without a source (lanes 0 of a row here, 0..2 after the next two
+    // steps) takes 0 for it and holds garbage from then on, but only lanes 3, 7, 11, 15 of a row feed the
+    // steps that follow, and all their sources exist -- so the destination needs no initial copy of v
+    asm("s_nop 1\n\t" // v may have been written by the instruction before (DPP source: two wait states)
+        "v_max_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
         "v_max_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
         "v_max_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
@@ -109,9 +111,19 @@ __device__ __forceinline__ float wave_max(float v)
         float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
 }
 
+// five candidates in two v_max3_f32 (the tree max(max(a, b), max(c, d)) has the shorter chain but is three
+// instructions, and the row is bound by VALU issue -- a v_max* costs 4.2 SIMD cycles on gfx950 whatever its
+// operand count: profiles/r03/valu_issue.txt); max is exact, so the grouping changes no result
+// (written as asm: left to itself the compiler rebalances the chain of fmaxf into that tree here)
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float max5(float a, float b, float c, float d, float e)
 {
-    return fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), e);
+    return vmax3(vmax3(a, b, c), d, e);
 }
 
 // ---- vector loads of R consecutive floats ----------------------------------
@@ -260,7 +272,7 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                                          LaneSpecial const &sp, float const xEB,
                                          Exchange<(W > 1 ? W : 1)> *xc,
                                          unsigned wave, unsigned lane,
-                                         unsigned &gen, Fetch &&fetch)
+                                         unsigned &gen, unsigned const exact_e, Fetch &&fetch)
 {
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5,
                   s4 = (PH + 1) % 5, s5 = PH;
@@ -283,6 +295,21 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     fetch();
     __builtin_amdgcn_sched_barrier(0);
 
+    // E(j), one wavefront per pair: the maximum over the MATCH states, taken before the delete chain (its seven
+    // cross-lane steps no longer wait for the chain's fixed point).  With MD, DD <= 0 -- every profile whose
+    // transitions are log-probabilities -- D_k <= max_{i<k} M_i (an add of a non-positive number never rounds
+    // up), so the delete states cannot decide the maximum; a profile flagged DCP_PROF_EXACT_E at upload adds
+    // them below (wave-uniform branch).  max is exact, so the order of its operands changes nothing.
+    float E = ni;
+    if constexpr (W == 1)
+    {
+        float em = m[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            em = fmaxf(em, m[r]);
+        E = wave_max(em);
+    }
+
     // Delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
     // a lane; across lanes (and wavefronts) iterate to the fixed point, which
     // is the sequential recurrence's unique solution -- exact, no reassociation.
@@ -296,13 +323,35 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     for (int r = 1; r < R; ++r)
         a[r] = m[r - 1] + t.md[r];
     auto refine = [&]() {
-        a[0] = shr1_add<XW>(m[R - 1], m_first, t.md[0]);
-        for (;;)
+        if constexpr (W == 1)
         {
-            float const d0 = fmaxf(a[0], shr1_add<XW>(d[R - 1], d_first, t.dd[0]));
-            if (!__any(d0 != d[0])) break;
-            d[0] = d0;
-            chain_rest<R>(a, d, t.dd);
+            // D only grows from pass to pass, so the first node's new value is max(old, D of lane - 1 + DD) and
+            // it changed exactly where that candidate exceeds the old value: test, then update in place
+            // (no second register for the new value, no copy at the loop's back edge)
+            for (;;)
+            {
+                float const c0 = shr1_add<XW>(d[R - 1], d_first, t.dd[0]);
+                // compare FIRST, then the in-place maximum (as asm: the scheduler puts the maximum first,
+                // which costs a second register and a copy per pass); all 64 lanes are active
+                unsigned long long changed;
+                asm("v_cmp_gt_f32_e64 %0, %2, %1\n\t"
+                    "v_max_f32_e32 %1, %1, %2"
+                    : "=&s"(changed), "+v"(d[0])
+                    : "v"(c0));
+                if (changed == 0ull) break;
+                chain_rest<R>(a, d, t.dd);
+            }
+        }
+        else
+        {
+            a[0] = shr1_add<XW>(m[R - 1], m_first, t.md[0]);
+            for (;;)
+            {
+                float const d0 = fmaxf(a[0], shr1_add<XW>(d[R - 1], d_first, t.dd[0]));
+                if (!__any(d0 != d[0])) break;
+                d[0] = d0;
+                chain_rest<R>(a, d, t.dd);
+            }
         }
     };
     auto lane_max = [&]() {
@@ -318,10 +367,22 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     refine();
 
     // E = max over nodes of M_k and D_k (exit scores are 0: protein_model.c:441-458)
-    float E;
     if constexpr (W == 1)
     {
-        E = wave_max(lane_max());
+        // (opaque: hoisted out of the row loops the condition lives as a lane mask and every row re-derives it
+        // through a v_cndmask / v_cmp pair; this way it is one s_cmp + s_cbranch)
+        unsigned xe = exact_e;
+        asm volatile("" : "+s"(xe));
+        if (__builtin_expect(xe != 0u, 0))
+        {
+            float ed = d[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                ed = fmaxf(ed, d[r]);
+            // (back into an SGPR: merged with the common path as a VALU result, E would live in a VGPR and
+            // the common path would pay a v_mov per row)
+            E = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(E, wave_max(ed)))));
+        }
     }
     else
     {
@@ -402,21 +463,37 @@ __device__ __forceinline__ unsigned base_at(uint32_t const *__restrict__ words, 
 // through an empty asm so that its zero-extension stays next to the load: hoisted out of the row
 // loop as a 64-bit value it no longer matches that addressing mode.)
 typedef char const __attribute__((address_space(1))) *gchar_ptr;
-template <int R>
+// STAGED > 0: the table's first STAGED rows -- the 4 + 16 rows of the one- and two-base words, which two of a
+// DP row's five reads go to -- sit in the block's LDS (`stg`, same [code][ldk] layout): they are the rows
+// every query of the profile keeps re-reading, and out of LDS they cost the L1 / L2 path nothing.
+constexpr int kStageRows = 20; // codes 0..19: words of one and two bases
+typedef float const __attribute__((address_space(3))) *lds_cfloat_ptr;
+template <int R, int STAGED>
 __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
-                                         unsigned ldk, unsigned lane_boff,
+                                         unsigned ldk, unsigned &lane_boff,
                                          cfloat *eN_tab, cfloat *eI_tab,
                                          unsigned w, float (&em)[5][R],
-                                         float (&eN)[5], float (&eI)[5])
+                                         float (&eN)[5], float (&eI)[5], float const *stg)
 {
     asm volatile("" : "+v"(lane_boff));
 #pragma unroll
     for (int l = 1; l <= 5; ++l)
     {
         unsigned const c = code_of(w, l);
-        gchar_ptr row = (gchar_ptr)em_base + c * ldk * 4u; // < 2^32: 1364 codes x 4096 nodes x 4 B
-        asm volatile("" : "+s"(row));
-        VecLoad<R>::ld((float const *)(row + lane_boff), em[l - 1]);
+        if (STAGED > 0 && (l == 1 ? 4 : l == 2 ? 20 : 84) <= STAGED)
+        {
+            // the row's byte offset as ONE scalar value (left alone, the constant part of a two-base word's
+            // row becomes a second per-lane add: ds_read2's offset fields are too narrow for it)
+            unsigned roff = c * ldk * 4u;
+            asm volatile("" : "+s"(roff));
+            VecLoad<R>::ld((float const *)((char const *)stg + (roff + lane_boff)), em[l - 1]);
+        }
+        else
+        {
+            gchar_ptr row = (gchar_ptr)em_base + c * ldk * 4u; // < 2^32: 1364 codes x 4096 nodes x 4 B
+            asm volatile("" : "+s"(row));
+            VecLoad<R>::ld((float const *)(row + lane_boff), em[l - 1]);
+        }
         eN[l - 1] = eN_tab[c];
         eI[l - 1] = eI_tab[c];
     }
@@ -434,11 +511,19 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 // ============================================================================
 // wavefronts per SIMD the register allocation must leave room for (512 VGPRs per SIMD lane)
 constexpr int rs_min_waves(int R) { return R <= 4 ? 4 : 2; }
-template <int R, int W>
+// PAIR (W == 1 only): the tasks are the (query, profile) pairs of a device-side list -- the pairs the query-lane
+// kernel could not finish (dcp_qlane.hip) -- and every wavefront strides over that list on its own.  Otherwise
+// (grid mode) a block's four wavefronts score four consecutive queries against ONE profile, whose one- and
+// two-base emission rows they first copy to LDS together.
+template <int R, int W, bool PAIR>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
+    static_assert(W == 1 || !PAIR, "W > 1 decides pair mode at run time");
     constexpr unsigned TASKS_PER_BLOCK = W == 1 ? 4u : 1u;
+    constexpr int STAGED = (W == 1 && !PAIR) ? kStageRows : 0;
     __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
+    __shared__ __attribute__((aligned(16))) float stage_mem[STAGED > 0 ? STAGED * 64 * R : 4];
+    float const *const stg = stage_mem;
     Exchange<(W > 1 ? W : 1)> *xc = &xc_mem;
     unsigned const lane = threadIdx.x & 63u;
     unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -448,11 +533,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
     // same few profiles).  Placement only affects speed, never results.
     unsigned const nblk = gridDim.x; // multiple of 8
     unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    unsigned task = W == 1 ? vblk * TASKS_PER_BLOCK + wave : vblk;
-    // pair mode: the grid is persistent and strides over a device-side list of (query,
-    // profile) pairs -- the pairs the query-lane kernel could not finish (dcp_qlane.hip)
-    bool const pair_mode = a.pairs != nullptr;
-    unsigned const ntasks = pair_mode ? min(*a.npairs, a.pair_cap) : a.nprof * a.nchunks;
+    bool const pair_mode = W == 1 ? PAIR : a.pairs != nullptr;
+    // grid mode, W == 1: block -> (profile, group of four chunks); a profile's chunk count is rounded up to whole
+    // blocks, so the wavefronts of a block always share the profile (the last block's spare wavefronts only help
+    // with the staging)
+    unsigned const bpp = W == 1 ? (a.nchunks + 3u) >> 2 : 1u; // blocks per profile
+    unsigned task = W == 1 && PAIR ? vblk * TASKS_PER_BLOCK + wave : vblk;
+    unsigned const ntasks = pair_mode ? min(*a.npairs, a.pair_cap) : W == 1 ? a.nprof * bpp : a.nprof * a.nchunks;
     for (; task < ntasks; task += nblk * TASKS_PER_BLOCK) // uniform per task: whole block for W > 1
     {
     unsigned slot, q0, q1;
@@ -460,6 +547,14 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
     {
         dcp_pair const pr = a.pairs[task];
         slot = pr.slot, q0 = pr.q, q1 = pr.q + 1u;
+    }
+    else if constexpr (W == 1)
+    {
+        unsigned const s_rel = task / bpp;
+        unsigned const chunk = (task - s_rel * bpp) * 4u + wave;
+        slot = a.first_prof + s_rel;
+        q0 = min(chunk * a.qchunk, a.nseqs); // a spare wavefront: q0 == q1
+        q1 = min(q0 + a.qchunk, a.nseqs);
     }
     else
     {
@@ -478,9 +573,22 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
     float const *__restrict__ em_base = a.emis_match + pm.emis_off;
     cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
     cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
-    unsigned const ldk = pm.ldk;
+    unsigned const ldk = W == 1 ? 64u * R : pm.ldk; // one wavefront per pair: the class capacity
+    // wave-uniform and opaque: a scalar compare and branch per row (as a plain bool the condition is
+    // re-materialised through a v_cndmask / v_cmp pair in every row)
+    unsigned const exact_e = __builtin_amdgcn_readfirstlane(pm.flags & DCP_PROF_EXACT_E);
     unsigned const lane_off = ((W == 1 ? 0u : wave * 64u) + lane) * R;
     unsigned gen = 0;
+    if constexpr (STAGED > 0)
+    {
+        // the first STAGED rows of the table are contiguous: [code][ldk]
+        float4 const *__restrict__ src = reinterpret_cast<float4 const *>(em_base);
+        float4 *dst = reinterpret_cast<float4 *>(stage_mem);
+#pragma unroll
+        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * 16u * R; i += 256u)
+            dst[i] = src[i];
+        __syncthreads();
+    }
     if constexpr (W > 1)
     {
         __syncthreads(); // pair mode: the previous task's last exchange is over
@@ -512,7 +620,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
         sp.a = x == 1u ? xt[DCP_X_EJ] : x == 2u ? xt[DCP_X_EC] : ni;
         sp.b = x == 0u ? xt[DCP_X_NN] : x == 1u ? xt[DCP_X_JJ] : x == 2u ? xt[DCP_X_CC] : xt[DCP_X_RR];
         sp.c = x == 0u ? xt[DCP_X_NB] : x == 1u ? xt[DCP_X_JB] : ni;
-        float const xEB = xt[DCP_X_EB];
+        float xEB = xt[DCP_X_EB];
+        asm volatile("" : "+v"(xEB)); // a VGPR: E(j) arrives in an SGPR, and an add takes only one
 
         // row 0: S = 0, B = S + SB, everything else -inf
         PairState<R> s;
@@ -535,7 +644,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
 
         float em[5][R], eN[5], eI[5];
         unsigned w = base_at(words, 0);
-        load_row<R>(em_base, ldk, lane_off * 4u, eN_tab, eI_tab, w, em, eN, eI);
+        unsigned lane_boff = lane_off * 4u; // pinned in place by load_row's asm (by value it is copied per row)
+        load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, eN, eI, stg);
         RowOut o{ni, ni};
         unsigned j = 1;
 
@@ -544,8 +654,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
 #define DCP_ROW(PH)                                                            \
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
-        o = dp_row<R, W, PH>(s, t, em, eN, eI, sp, xEB, xc, wave, lane, gen, [&]() { \
-            load_row<R>(em_base, ldk, lane_off * 4u, eN_tab, eI_tab, w, em, eN, eI); \
+        o = dp_row<R, W, PH>(s, t, em, eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
+            load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, eN, eI, stg); \
         });                                                                    \
         ++j;                                                                   \
     }
@@ -578,7 +688,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
             }
         }
     }
-    if (!pair_mode) break; // grid mode: one task per wavefront (W == 1) or block
+    if (!pair_mode) break; // grid mode: one task per block
     }
 }
 
@@ -1112,12 +1222,26 @@ extern "C" void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles,
 template <int R, int W>
 static void launch_rs(dcp_scan_args const *a, unsigned nblocks, hipStream_t s)
 {
-    hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W>), dim3(nblocks),
-                       dim3(W == 1 ? 256 : 64 * W), 0, s, *a);
+    if constexpr (W == 1)
+    {
+        if (a->pairs)
+            hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, 1, true>), dim3(nblocks), dim3(256), 0, s, *a);
+        else
+            hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, 1, false>), dim3(nblocks), dim3(256), 0, s, *a);
+    }
+    else
+        hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W, false>), dim3(nblocks), dim3(64 * W), 0, s, *a);
 }
 
 // tasks per block of the (R, W) kernel: 4 independent wavefronts when W == 1
 extern "C" unsigned dcp_rowsweep_tasks_per_block(int W) { return W == 1 ? 4u : 1u; }
+
+extern "C" uint64_t dcp_rowsweep_grid_blocks(int W, unsigned nprof, unsigned nchunks)
+{
+    // W == 1: a profile's chunks are rounded up to whole four-wavefront blocks (the kernel's task map)
+    uint64_t const n = W == 1 ? (uint64_t)nprof * ((nchunks + 3u) >> 2) : (uint64_t)nprof * nchunks;
+    return (n + 7u) / 8u * 8u;
+}
 
 extern "C" int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a,
                                    unsigned nblocks, void *stream)
