@@ -177,6 +177,7 @@ def _load(path=None, hooks=False):
     }
     if hooks:
         sig["dcp_gpu_test_set_redo_cap"] = (I, [P, U])
+        sig["dcp_gpu_test_set_rowsweep_variant"] = (I, [P, I, U])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -560,6 +561,10 @@ class Scanner:
         """TEST-ONLY, and only on a Scanner of the test-hooks build (load_testhooks): shrink the redo lists
         (0 restores 2^26) to reach the overflow path."""
         self._check(self._lib.dcp_gpu_test_set_redo_cap(self._c, int(cap)))
+
+    def test_set_rowsweep_variant(self, stage_rows, block_waves=0):
+        """TEST-ONLY (test-hooks build): force the grid-mode row-sweep kernel variant; stage_rows < 0: automatic."""
+        self._check(self._lib.dcp_gpu_test_set_rowsweep_variant(self._c, int(stage_rows), int(block_waves)))
 
     @property
     def last_scan_ms(self):

@@ -37,10 +37,10 @@ struct SizeClass
 // (profiles/r02/rowsweep_tuning.txt).
 constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {7, 1}, {8, 1},
                                   {3, 4}, {4, 4}, {3, 8}, {4, 8}, {3, 16}, {4, 16}};
-// cells/s of each class on a full grid, measured on the C3 and C5 DBs (profiles/r02/rowsweep_tuning.txt): the
-// kernel choice prices a row-sweep scan with them
-constexpr double kClassRate[] = {530e9, 720e9, 930e9, 1030e9, 940e9, 980e9, 1000e9, 1000e9,
-                                 490e9, 600e9, 440e9, 570e9, 400e9, 400e9};
+// cells/s of each class on a full grid, measured on the C3 DB (profiles/r03/rowsweep_variants.txt; round 2:
+// profiles/r02/rowsweep_tuning.txt): the kernel choice prices a row-sweep scan with them
+constexpr double kClassRate[] = {600e9, 850e9, 1040e9, 1180e9, 1030e9, 1120e9, 1190e9, 1215e9,
+                                 480e9, 625e9, 425e9, 530e9, 400e9, 400e9};
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
 static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
 static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
@@ -113,6 +113,9 @@ struct dcp_gpu_ctx
     uint32_t *h_qstage = nullptr;
     size_t h_qstage_n = 0;
     hipEvent_t ev_qstage = nullptr;       // recorded behind the copies: the buffer may be rewritten after it
+    int rs_force_stg = -1;                // test hook: row-sweep variant (rows staged, wavefronts per block)
+    unsigned rs_force_bw = 0;
+    unsigned rs_pad_lds = 0;
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
@@ -818,6 +821,48 @@ int dcp_gpu_hit_buffer(dcp_gpu_ctx *c, void **hits_dev, void **nhits_dev, unsign
     return DCP_OK;
 }
 
+// Which grid-mode row-sweep kernel scores one size class against `nchunks` queries: rows of the emission table
+// each block stages in LDS and wavefronts per block (dcp_kernels.hip).  Measured on the 20 000-profile DB
+// (profiles/r03/rowsweep_variants.txt, ms per scan for 1 .. 1 000 queries):
+//   * small batches stream the tables from HBM (an XCD's 512 wavefront slots work on far more profiles than its
+//     4 MB L2 holds tables of), so what a block keeps in LDS is traffic saved: with the three-base rows staged
+//     as well, 8 queries take 49 ms instead of 57, 16: 80 instead of 99, 32: 142 instead of 160 -- provided the
+//     block is wide enough that the 21.5 KB x R image does not cost wavefront slots (one profile per block);
+//   * from about 40 queries on the L2 serves the rows and the 20-row image with narrower blocks wins (64 queries:
+//     259 vs 270 ms); wide blocks start and drain together, which a long launch pays for (1 000 queries: 3.65 s
+//     with 4 wavefronts per block, 3.83 with 8, 4.14 with 16).
+static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunks, int *stg, unsigned *bw)
+{
+    if (W != 1)
+    {
+        *stg = 0, *bw = 1;
+        return;
+    }
+    // blocks of equal width: 24 queries are two blocks of 12 wavefronts, not 16 + 8
+    auto balanced = [&](unsigned maxw) {
+        unsigned const nb = (nchunks + maxw - 1u) / maxw;
+        return (nchunks + nb - 1u) / nb;
+    };
+    int g = 20;
+    unsigned w = balanced(nchunks <= 80u ? 8u : 4u);
+    unsigned const max84 = dcp_rowsweep_max_block_waves(R, W, 84);
+    if (nchunks >= 6u && nchunks <= 36u && max84 != 0u)
+    {
+        unsigned const w84 = balanced(max84);
+        unsigned const slots = R <= 4 ? 16u : 8u; // wavefronts of this class a CU runs at the kernel's register count
+        unsigned const blocks = (160u * 1024u) / dcp_rowsweep_stage_bytes(R, 84);
+        // the image may cost up to half of them: such a batch waits for HBM, not for issue slots (8 queries with
+        // the R = 4 class at 8 of 16 wavefronts per CU: 49 ms; with that class on the 20-row image: 51)
+        if (std::min(blocks * w84, slots) * 2u >= slots) g = 84, w = w84;
+    }
+    if (c->rs_force_stg >= 0 && dcp_rowsweep_max_block_waves(R, W, c->rs_force_stg) != 0u)
+    {
+        g = c->rs_force_stg;
+        w = g == 0 ? 4u : std::min(std::min(c->rs_force_bw ? c->rs_force_bw : 4u, dcp_rowsweep_max_block_waves(R, W, g)), nchunks);
+    }
+    *stg = g, *bw = std::max(1u, w);
+}
+
 int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsigned q_begin,
                        unsigned q_end)
 {
@@ -906,9 +951,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             //                67 + 36) + the last task's row chain
             //   query lane   max(longest task, all tile rows / resident blocks); a tile row of a block
             //                takes 0.52 us with one busy wavefront, 0.73 us with four.
-            // On the 20k-profile DB the switch comes at about 115 queries (96 queries: 427 vs 510 ms,
-            // 128: 561 vs 514 ms); a DB of a few hundred profiles stays with the row sweep up to
-            // several hundred queries (its tasks cannot fill the grid).
+            // On the 20k-profile DB the switch comes at about 150 queries since round 3 (128 queries: 484 ms in
+            // the row sweep, 480 in the single-stage query-lane kernel; round 2: at about 115); a DB of a few
+            // hundred profiles stays with the row sweep up to several hundred queries (its tasks cannot fill the grid).
             unsigned const NTq = ql_nt;
             std::vector<unsigned> len(c->seq_len.begin() + q_begin, c->seq_len.begin() + q_end);
             std::sort(len.begin(), len.end());
@@ -923,7 +968,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             for (int k = 0; k < kNumClasses; ++k)
                 t_rs += (double)c->class_core[k] * sum_len / kClassRate[k];
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
-            double const trow = (w3 ? 0.56 : 0.52 + 0.07 * (waves - 1u)) * 1e-6; // w3: + one add per gather
+            // (round 3, 20k-profile DB: 96 and 128 queries 477 / 480 ms, 256 queries 659 ms in the single-stage kernel)
+            static double const kTrow[4] = {0.52, 0.54, 0.64, 0.73};
+            double const trow = (w3 ? 0.56 : kTrow[waves - 1u]) * 1e-6; // w3: + one add per gather
             double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
             double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
                                          (double)c->sum_tiles * sum_block_lmax * trow / resident) +
@@ -1136,10 +1183,13 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         a.nprof = last - first;
         SizeClass const sc = kClasses[k];
         uint64_t const ntasks = (uint64_t)a.nprof * a.nchunks;
-        uint64_t const nblocks = dcp_rowsweep_grid_blocks(sc.W, a.nprof, a.nchunks);
-        if (ntasks > 0xffffffffull || nblocks > 0x7fffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
-        if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)nblocks, ls))
-            return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
+        if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
+        int stg;
+        unsigned bw;
+        rowsweep_variant(c, sc.R, sc.W, a.nchunks, &stg, &bw);
+        if (int lrc = dcp_launch_rowsweep_grid(sc.R, sc.W, &a, stg, bw, ls, c->rs_pad_lds))
+            return lrc == -2 ? c->fail(DCP_EINVAL, "scan too large for one launch")
+                             : c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d (stage %d, %u wavefronts)", sc.R, sc.W, stg, bw);
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
         if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_class[c->n_launched], 0));
         c->launched_class[c->n_launched++] = k;
@@ -1151,6 +1201,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     return DCP_OK;
 }
 
+// (declared above dcp_gpu_scan_range)
 // Wait for the stream; after a query-lane scan also look at the redo counters.  A redo list
 // that overflowed (> 2^26 pairs of one size class needed the row sweep) lost pairs: the scan is
 // repeated with the row-sweep kernel, which needs no list.
@@ -1174,6 +1225,14 @@ static int finish_scan(dcp_gpu_ctx *c)
 }
 
 #ifdef DCP_TEST_HOOKS
+int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
+{
+    if (!c) return DCP_EINVAL;
+    c->rs_force_stg = stg;
+    c->rs_force_bw = bw & 0xffu;
+    c->rs_pad_lds = (bw >> 8) * 1024u; // bits 8..: KiB of unused LDS per block (fewer blocks per CU)
+    return DCP_OK;
+}
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)
 {
     if (!c) return DCP_EINVAL;

@@ -167,8 +167,12 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
-// blocks of a grid-mode launch (all queries x the profiles of one size class); a multiple of 8
-uint64_t dcp_rowsweep_grid_blocks(int W, unsigned nprof, unsigned nchunks);
+// grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
+// (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large
+int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,
+                             unsigned pad_lds); // pad_lds: unused dynamic LDS per block (occupancy experiments), normally 0
+unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg); // 0: no kernel stages `stg` rows for this class
+unsigned dcp_rowsweep_stage_bytes(int R, int stg);
 int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream); // nt: 64, 128 or 256 queries per block
 // two-stage variant: 512-thread blocks, one per CU; != 0 if the kernel cannot be configured
 int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream);

@@ -14,6 +14,7 @@
 #include "dcp_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 namespace
 {
@@ -466,7 +467,6 @@ typedef char const __attribute__((address_space(1))) *gchar_ptr;
 // STAGED > 0: the table's first STAGED rows -- the 4 + 16 rows of the one- and two-base words, which two of a
 // DP row's five reads go to -- sit in the block's LDS (`stg`, same [code][ldk] layout): they are the rows
 // every query of the profile keeps re-reading, and out of LDS they cost the L1 / L2 path nothing.
-constexpr int kStageRows = 20; // codes 0..19: words of one and two bases
 typedef float const __attribute__((address_space(3))) *lds_cfloat_ptr;
 template <int R, int STAGED>
 __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
@@ -480,7 +480,7 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
     for (int l = 1; l <= 5; ++l)
     {
         unsigned const c = code_of(w, l);
-        if (STAGED > 0 && (l == 1 ? 4 : l == 2 ? 20 : 84) <= STAGED)
+        if (STAGED > 0 && (l == 1 ? 4 : l == 2 ? 20 : l == 3 ? 84 : 1364) <= STAGED) // the staged rows hold all words of l bases
         {
             // the row's byte offset as ONE scalar value (left alone, the constant part of a two-base word's
             // row becomes a second per-lane add: ds_read2's offset fields are too narrow for it)
@@ -511,16 +511,20 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 // ============================================================================
 // wavefronts per SIMD the register allocation must leave room for (512 VGPRs per SIMD lane)
 constexpr int rs_min_waves(int R) { return R <= 4 ? 4 : 2; }
-// PAIR (W == 1 only): the tasks are the (query, profile) pairs of a device-side list -- the pairs the query-lane
-// kernel could not finish (dcp_qlane.hip) -- and every wavefront strides over that list on its own.  Otherwise
-// (grid mode) a block's four wavefronts score four consecutive queries against ONE profile, whose one- and
-// two-base emission rows they first copy to LDS together.
-template <int R, int W, bool PAIR>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterbi_rowsweep_kernel(dcp_scan_args a)
+// STG (W == 1 only): leading rows of the profile's emission table a block keeps in LDS -- 20 (the words of one
+// and two bases) or 84 (three bases as well).  A staged block is 1..16 wavefronts (blockDim.x / 64) scoring
+// consecutive queries against ONE profile, whose rows they first copy together; it is sized by the launcher so
+// that the CU's wavefront slots stay filled although an 84-row image takes 21.5 KB x R of its LDS.
+// STG == 0: every wavefront has its own task -- a (query, profile) pair of a device-side list (the pairs the
+// query-lane kernel could not finish, dcp_qlane.hip: a persistent grid strides over the list) or, without a
+// list, chunk `task % nchunks` of profile `task / nchunks`.
+constexpr int rs_block_threads(int R, int W, int STG) { return W > 1 ? 64 * W : STG > 0 ? (R <= 4 ? 1024 : 512) : 256; }
+template <int R, int W, int STG>
+__global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R)) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
-    static_assert(W == 1 || !PAIR, "W > 1 decides pair mode at run time");
-    constexpr unsigned TASKS_PER_BLOCK = W == 1 ? 4u : 1u;
-    constexpr int STAGED = (W == 1 && !PAIR) ? kStageRows : 0;
+    static_assert(W == 1 || STG == 0, "only one-wavefront pairs stage rows");
+    constexpr unsigned TASKS_PER_BLOCK = (W == 1 && STG == 0) ? 4u : 1u;
+    constexpr int STAGED = STG;
     __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
     __shared__ __attribute__((aligned(16))) float stage_mem[STAGED > 0 ? STAGED * 64 * R : 4];
     float const *const stg = stage_mem;
@@ -533,14 +537,14 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
     // same few profiles).  Placement only affects speed, never results.
     unsigned const nblk = gridDim.x; // multiple of 8
     unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    bool const pair_mode = W == 1 ? PAIR : a.pairs != nullptr;
-    // grid mode, W == 1: block -> (profile, group of four chunks); a profile's chunk count is rounded up to whole
-    // blocks, so the wavefronts of a block always share the profile (the last block's spare wavefronts only help
-    // with the staging)
-    unsigned const bpp = W == 1 ? (a.nchunks + 3u) >> 2 : 1u; // blocks per profile
-    unsigned task = W == 1 && PAIR ? vblk * TASKS_PER_BLOCK + wave : vblk;
-    unsigned const ntasks = pair_mode ? min(*a.npairs, a.pair_cap) : W == 1 ? a.nprof * bpp : a.nprof * a.nchunks;
-    for (; task < ntasks; task += nblk * TASKS_PER_BLOCK) // uniform per task: whole block for W > 1
+    bool const pair_mode = STAGED > 0 ? false : a.pairs != nullptr;
+    // staged: block -> (profile, group of `bw` chunks); a profile's chunk count is rounded up to whole blocks, so
+    // the wavefronts of a block always share the profile (the last block's spare wavefronts only help with the copy)
+    unsigned const bw = STAGED > 0 ? blockDim.x >> 6 : 1u;
+    unsigned const bpp = STAGED > 0 ? (a.nchunks + bw - 1u) / bw : 1u; // blocks per profile
+    unsigned task = TASKS_PER_BLOCK > 1u ? vblk * TASKS_PER_BLOCK + wave : vblk;
+    unsigned const ntasks = pair_mode ? min(*a.npairs, a.pair_cap) : STAGED > 0 ? a.nprof * bpp : a.nprof * a.nchunks;
+    for (; task < ntasks; task += nblk * TASKS_PER_BLOCK) // uniform per task: whole block for W > 1 and staged blocks
     {
     unsigned slot, q0, q1;
     if (pair_mode)
@@ -548,10 +552,10 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
         dcp_pair const pr = a.pairs[task];
         slot = pr.slot, q0 = pr.q, q1 = pr.q + 1u;
     }
-    else if constexpr (W == 1)
+    else if constexpr (STAGED > 0)
     {
         unsigned const s_rel = task / bpp;
-        unsigned const chunk = (task - s_rel * bpp) * 4u + wave;
+        unsigned const chunk = (task - s_rel * bpp) * bw + wave;
         slot = a.first_prof + s_rel;
         q0 = min(chunk * a.qchunk, a.nseqs); // a spare wavefront: q0 == q1
         q1 = min(q0 + a.qchunk, a.nseqs);
@@ -584,8 +588,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W, rs_min_waves(R)) void viterb
         // the first STAGED rows of the table are contiguous: [code][ldk]
         float4 const *__restrict__ src = reinterpret_cast<float4 const *>(em_base);
         float4 *dst = reinterpret_cast<float4 *>(stage_mem);
-#pragma unroll
-        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * 16u * R; i += 256u)
+        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * 16u * R; i += blockDim.x)
             dst[i] = src[i];
         __syncthreads();
     }
@@ -1219,30 +1222,63 @@ extern "C" void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles,
                        (hipStream_t)stream, *a);
 }
 
-template <int R, int W>
-static void launch_rs(dcp_scan_args const *a, unsigned nblocks, hipStream_t s)
+template <int R, int W, int STG>
+static void launch_rs(dcp_scan_args const *a, unsigned nblocks, unsigned threads, hipStream_t s, unsigned pad_lds = 0)
 {
-    if constexpr (W == 1)
-    {
-        if (a->pairs)
-            hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, 1, true>), dim3(nblocks), dim3(256), 0, s, *a);
-        else
-            hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, 1, false>), dim3(nblocks), dim3(256), 0, s, *a);
-    }
-    else
-        hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W, false>), dim3(nblocks), dim3(64 * W), 0, s, *a);
+    // pad_lds: unused dynamic LDS -- fewer blocks per CU (an occupancy experiment of the tests' build)
+    hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W, STG>), dim3(nblocks), dim3(threads), pad_lds, s, *a);
 }
 
-// tasks per block of the (R, W) kernel: 4 independent wavefronts when W == 1
+// tasks per block of the unstaged (R, W) kernel: 4 independent wavefronts when W == 1
 extern "C" unsigned dcp_rowsweep_tasks_per_block(int W) { return W == 1 ? 4u : 1u; }
 
-extern "C" uint64_t dcp_rowsweep_grid_blocks(int W, unsigned nprof, unsigned nchunks)
+// Is there a kernel that stages `stg` rows for this class, and how many wavefronts may its block have?
+extern "C" unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg)
 {
-    // W == 1: a profile's chunks are rounded up to whole four-wavefront blocks (the kernel's task map)
-    uint64_t const n = W == 1 ? (uint64_t)nprof * ((nchunks + 3u) >> 2) : (uint64_t)nprof * nchunks;
-    return (n + 7u) / 8u * 8u;
+    if (W != 1) return stg == 0 ? 1u : 0u;
+    if (stg == 0) return 4u;
+    if (stg == 20) return R >= 1 && R <= 8 ? (R <= 4 ? 16u : 8u) : 0u;
+    if (stg == 84) return R >= 1 && R <= 7 ? (R <= 4 ? 16u : 8u) : 0u; // R = 8: 172 KB
+    return 0u;
+}
+extern "C" unsigned dcp_rowsweep_stage_bytes(int R, int stg) { return (unsigned)stg * 64u * (unsigned)R * 4u; }
+
+// Grid mode: all chunks x the profiles [first_prof, first_prof + nprof) of one size class.
+//   stg  rows staged in LDS (0: every wavefront its own task, four per block);
+//   bw   wavefronts per staged block (1..dcp_rowsweep_max_block_waves).
+extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,
+                                        unsigned pad_lds)
+{
+    hipStream_t s = (hipStream_t)stream;
+    unsigned const maxw = dcp_rowsweep_max_block_waves(R, W, stg);
+    if (maxw == 0u || (stg > 0 && (bw == 0u || bw > maxw))) return -1;
+    uint64_t nb;
+    if (stg > 0) nb = (uint64_t)a->nprof * ((a->nchunks + bw - 1u) / bw);
+    else nb = ((uint64_t)a->nprof * a->nchunks + dcp_rowsweep_tasks_per_block(W) - 1u) / dcp_rowsweep_tasks_per_block(W);
+    nb = (nb + 7u) / 8u * 8u;
+    if (nb > 0x7fffffffull) return -2;
+    unsigned const nblocks = (unsigned)nb;
+    {
+        // a block's LDS ends at 160 KiB: a dispatch asking for more aborts the queue
+        unsigned const used = dcp_rowsweep_stage_bytes(R, stg) + 1024u;
+        pad_lds = used >= 160u * 1024u ? 0u : std::min(pad_lds, 160u * 1024u - used);
+    }
+#define DCP_CASE_S(r, g)                                                       \
+    if (R == r && W == 1 && stg == g)                                          \
+    {                                                                          \
+        launch_rs<r, 1, g>(a, nblocks, 64u * bw, s, pad_lds);                  \
+        return 0;                                                              \
+    }
+    DCP_CASE_S(1, 20) DCP_CASE_S(2, 20) DCP_CASE_S(3, 20) DCP_CASE_S(4, 20) DCP_CASE_S(5, 20) DCP_CASE_S(6, 20)
+    DCP_CASE_S(7, 20) DCP_CASE_S(8, 20)
+    DCP_CASE_S(1, 84) DCP_CASE_S(2, 84) DCP_CASE_S(3, 84) DCP_CASE_S(4, 84) DCP_CASE_S(5, 84) DCP_CASE_S(6, 84)
+    DCP_CASE_S(7, 84)
+#undef DCP_CASE_S
+    if (stg != 0) return -1;
+    return dcp_launch_rowsweep(R, W, a, nblocks, stream);
 }
 
+// unstaged kernels: pair mode (a->pairs), the classes of several wavefronts per pair, and grid mode without staging
 extern "C" int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a,
                                    unsigned nblocks, void *stream)
 {
@@ -1250,7 +1286,7 @@ extern "C" int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a,
 #define DCP_CASE(r, w)                                                         \
     if (R == r && W == w)                                                      \
     {                                                                          \
-        launch_rs<r, w>(a, nblocks, s);                                        \
+        launch_rs<r, w, 0>(a, nblocks, w == 1 ? 256u : 64u * w, s);            \
         return 0;                                                              \
     }
     DCP_CASE(1, 1) DCP_CASE(2, 1) DCP_CASE(3, 1) DCP_CASE(4, 1) DCP_CASE(5, 1) DCP_CASE(6, 1) DCP_CASE(7, 1)

@@ -303,6 +303,11 @@ int dcp_gpu_hit_buffer(dcp_gpu_ctx *, void **hits_dev, void **nhits_dev, unsigne
  * (default 2^26 pairs; 0 restores it) so a test can reach the overflow path.  Results are unaffected:
  * an overflowed scan is repeated with the row-sweep kernel. */
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *, unsigned cap);
+/* Same build only.  Forces the grid-mode row-sweep kernel variant -- leading emission rows a block stages in
+ * LDS (0, 20 or 84) and wavefronts per block (0: the default) -- instead of the one the library picks per
+ * size class and batch size; stage < 0 restores the automatic choice.  A class without such a kernel keeps
+ * the automatic one.  Every variant computes the same scores: the parity tests run them all. */
+int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *, int stage_rows, unsigned block_waves);
 #endif
 /* Wait for the stream (and, after a query-lane scan, check its redo lists:
  * see dcp_gpu_last_scan_redo_pairs). */

@@ -366,7 +366,7 @@ def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
 def test_kernel_choice_by_batch_size(dcp, scanner):
     """kernel = 0 picks by a cost model: a DB of a few profiles cannot fill the query-lane kernel's
     persistent grid, so it stays with the row sweep at any batch size (the 20k-profile DB switches to the
-    query-lane kernel at about 115 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
+    query-lane kernel at about 150 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
     gives the same bits; launch infos tell the two apart."""
     rng = np.random.default_rng(48)
     profiles = make_profiles(dcp, [(900 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((3, 70, 130, 300))])
@@ -603,6 +603,41 @@ def test_positive_delete_transitions_keep_d_in_e(dcp, oracle32, scanner, kern, m
         assert scanner.last_scan_redo_pairs >= 3 * len(seqs)
     # the delete states really decide E for the flagged profiles: dropping them would change the score
     assert np.isfinite(oa).all()
+
+
+@pytest.mark.parametrize("stage,waves", [(0, 4), (20, 1), (20, 3), (20, 4), (20, 16), (84, 1), (84, 5), (84, 8), (84, 16)])
+def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves):
+    """Every grid-mode variant of the row sweep -- rows of the emission table a block keeps in LDS (none, the
+    one- and two-base words, the three-base words as well) x wavefronts per block (one profile per block: blocks
+    with spare wavefronts, a last block that is not full, more chunks than one block takes) -- against the
+    oracle's float32 recursion on the product's tables, bit for bit, over every one-wavefront size class, a
+    flagged (positive MD / DD) profile and multi-wavefront classes (which have one variant).  Forced through the
+    tests' own -DDCP_TEST_HOOKS build; the shipped library picks among the same kernels by batch size."""
+    rng = np.random.default_rng(4242)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    sizes = (1, 5, 64, 65, 127, 128, 150, 192, 250, 256, 257, 320, 384, 448, 449, 512, 600)
+    params = [pfam_like_params(rng, M) for M in sizes]
+    null, match, trans = pfam_like_params(rng, 90)
+    trans = trans.copy()
+    trans[1:90, 2] = np.float32(0.7)  # MD > 0: the delete states decide E(j)
+    trans[1:90, 6] = np.float32(0.4)
+    params.append((null, match, trans))
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    hooks_scanner.upload_db(profiles, expand_on_host=True)
+    try:
+        hooks_scanner.test_set_rowsweep_variant(stage, waves)
+        for nseq in (1, 3, 21):
+            seqs = rand_seqs(rng, nseq, 1, 150)
+            hooks_scanner.upload_seqs(seqs)
+            for multi in (True, False):
+                hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+                gn, ga = hooks_scanner.scores()
+                on, oa = oracle_dp_on_product_tables(dcp, oracle32, hooks_scanner, profiles, seqs, multi, False, True)
+                assert same_bits(gn, on) and same_bits(ga, oa), (stage, waves, nseq, multi)
+    finally:
+        hooks_scanner.test_set_rowsweep_variant(-1, 0)
 
 
 def test_qlane_at_block_scale(dcp, oracle32, scanner):
