@@ -577,18 +577,22 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R)) void 
     float const *__restrict__ em_base = a.emis_match + pm.emis_off;
     cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
     cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
-    unsigned const ldk = W == 1 ? 64u * R : pm.ldk; // one wavefront per pair: the class capacity
+    // Row length of the profile's tables.  W > 1: the class capacity.  W == 1: core_size + R rounded up to 4, so
+    // that every row (emissions and transitions alike) ends in at least R columns of -inf: a lane past the
+    // last node reads THOSE -- the same few bytes for all such lanes -- instead of owning padding columns of
+    // its own, and a row is 15 % shorter on a Pfam-like size distribution (dcp_gpu_db_upload).
+    unsigned const ldk = pm.ldk;
     // wave-uniform and opaque: a scalar compare and branch per row (as a plain bool the condition is
     // re-materialised through a v_cndmask / v_cmp pair in every row)
     unsigned const exact_e = __builtin_amdgcn_readfirstlane(pm.flags & DCP_PROF_EXACT_E);
-    unsigned const lane_off = ((W == 1 ? 0u : wave * 64u) + lane) * R;
+    unsigned const lane_off = W == 1 ? (lane * R < pm.core_size ? lane * R : ldk - R) : (wave * 64u + lane) * R;
     unsigned gen = 0;
     if constexpr (STAGED > 0)
     {
         // the first STAGED rows of the table are contiguous: [code][ldk]
         float4 const *__restrict__ src = reinterpret_cast<float4 const *>(em_base);
         float4 *dst = reinterpret_cast<float4 *>(stage_mem);
-        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * 16u * R; i += blockDim.x)
+        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * (ldk >> 2); i += blockDim.x) // ldk is a multiple of 4
             dst[i] = src[i];
         __syncthreads();
     }
@@ -872,9 +876,12 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
     }
 
     // ---- forward -----------------------------------------------------------------
-    unsigned const R = ldk / 64u; // nodes per lane, contiguous
+    // nodes per lane, contiguous; a one-wavefront profile's rows are not a multiple of 64 columns wide
+    // (dcp_gpu_db_upload), so the last lanes may own fewer nodes or none
+    unsigned const R = (ldk + 63u) / 64u;
     unsigned const k0 = lane * R;
-    for (unsigned r = 0; r < R; ++r)
+    unsigned const nr = k0 >= ldk ? 0u : (ldk - k0 < R ? ldk - k0 : R); // this lane's nodes
+    for (unsigned r = 0; r < nr; ++r)
         v.Mv[k0 + r] = v.Iv[k0 + r] = v.Dv[k0 + r] = ni; // row 0
     if (lane == 0)
     {
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
         unsigned const w = window_at(v.words, j);
         unsigned const maxl = j < 5u ? j : 5u;
         float *Mj = v.Mv + (size_t)j * ldk, *Ij = v.Iv + (size_t)j * ldk, *Dj = v.Dv + (size_t)j * ldk;
-        for (unsigned r = 0; r < R; ++r)
+        for (unsigned r = 0; r < nr; ++r)
         {
             unsigned const k = k0 + r;
             float m = ni, iv = ni;
@@ -909,17 +916,17 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
         {
             float const before = d_last;
             float d = lane_shr1(d_last, ni); // D of node k0-1
-            for (unsigned r = 0; r < R; ++r)
+            for (unsigned r = 0; r < nr; ++r)
             {
                 unsigned const k = k0 + r;
                 d = k == 0 ? ni : fmaxf(Mj[k - 1] + v.md[k], d + v.dd[k]);
                 Dj[k] = d;
             }
-            d_last = d;
+            d_last = nr ? d : ni; // a lane without nodes passes nothing on
             if (!__any(d_last != before)) break;
         }
         float e = ni;
-        for (unsigned r = 0; r < R; ++r)
+        for (unsigned r = 0; r < nr; ++r)
             e = fmaxf(e, fmaxf(Mj[k0 + r], Dj[k0 + r]));
         float const E = wave_max(e);
         float N = ni, J = ni, C = ni;
