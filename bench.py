@@ -653,15 +653,17 @@ def main():
                 "analytic_tile_image_bytes_per_launch": tile_bytes,
                 "compulsory_bytes_per_launch": compulsory,
             },
-            # the row sweep reads SURVEY 8d's 20 B/cell of match emissions from the XCD's L2 (the profile's table is
-            # L2-resident while its queries run; the rows of the 1- and 2-base words mostly hit the CU's L1):
-            # against the L2 peak (MI355X_MICROARCH.md: 34.5 TB/s; its measured rate for gathering L2-resident
-            # rows into LDS is 16.8-18.8 TB/s) -- that path, not HBM or the VALU, is this kernel's nearest bound
+            # the row sweep reads SURVEY 8d's 20 B/cell of match emissions on chip: since round 3 the rows of the
+            # 1- and 2-base words (8 of the 20 B) from the block's LDS image, the other 12 B/cell from the XCD's L2
+            # (the profile's table is L2-resident while its queries run): against the L2 peak
+            # (MI355X_MICROARCH.md: 34.5 TB/s; its measured rate for gathering L2-resident rows is 16.8-18.8 TB/s)
             "l2_gather": (None if is_qlane else {
-                "bytes_per_launch": int(dom_algo_bytes),
-                "gbs": round(dom_algo_bytes / (dom_ms * 1e-3) / 1e9, 1),
+                "bytes_per_launch": int(dom_algo_bytes * 12 / 20),
+                "bytes_per_cell": 12,
+                "gbs": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 1e9, 1),
                 "peak_gbs": 34500.0,
-                "frac": round(dom_algo_bytes / (dom_ms * 1e-3) / 34.5e12, 3),
+                "frac": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 34.5e12, 3),
+                "lds_bytes_per_cell": 8,
             }),
             # SURVEY.md 8d's per-pair byte model 20*M*L + 32*(M+1) + L + 8: NOT a bound for this design
             "algorithmic_hbm": {

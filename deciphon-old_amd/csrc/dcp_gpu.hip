@@ -116,6 +116,7 @@ struct dcp_gpu_ctx
     int rs_force_stg = -1;                // test hook: row-sweep variant (rows staged, wavefronts per block)
     unsigned rs_force_bw = 0;
     unsigned rs_pad_lds = 0;
+    int rs_force_pf = 0;
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
@@ -838,8 +839,9 @@ int dcp_gpu_hit_buffer(dcp_gpu_ctx *c, void **hits_dev, void **nhits_dev, unsign
 //   * from about 40 queries on the L2 serves the rows and the 20-row image with narrower blocks wins (64 queries:
 //     259 vs 270 ms); wide blocks start and drain together, which a long launch pays for (1 000 queries: 3.65 s
 //     with 4 wavefronts per block, 3.83 with 8, 4.14 with 16).
-static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunks, int *stg, unsigned *bw)
+static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunks, int *stg, unsigned *bw, int *pf)
 {
+    *pf = 0;
     if (W != 1)
     {
         *stg = 0, *bw = 1;
@@ -868,6 +870,9 @@ static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunk
         w = g == 0 ? 4u : std::min(std::min(c->rs_force_bw ? c->rs_force_bw : 4u, dcp_rowsweep_max_block_waves(R, W, g)), nchunks);
     }
     *stg = g, *bw = std::max(1u, w);
+    // two rows of prefetch: the batches that wait for HBM (the 84-row variants' range, and below it)
+    *pf = g > 0 && nchunks <= 36u;
+    if (c->rs_force_stg >= 0 && g > 0) *pf = c->rs_force_pf;
 }
 
 int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsigned q_begin,
@@ -1191,10 +1196,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         SizeClass const sc = kClasses[k];
         uint64_t const ntasks = (uint64_t)a.nprof * a.nchunks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
-        int stg;
+        int stg, pf;
         unsigned bw;
-        rowsweep_variant(c, sc.R, sc.W, a.nchunks, &stg, &bw);
-        if (int lrc = dcp_launch_rowsweep_grid(sc.R, sc.W, &a, stg, bw, ls, c->rs_pad_lds))
+        rowsweep_variant(c, sc.R, sc.W, a.nchunks, &stg, &bw, &pf);
+        if (int lrc = dcp_launch_rowsweep_grid(sc.R, sc.W, &a, stg, bw, ls, c->rs_pad_lds, pf))
             return lrc == -2 ? c->fail(DCP_EINVAL, "scan too large for one launch")
                              : c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d (stage %d, %u wavefronts)", sc.R, sc.W, stg, bw);
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
@@ -1237,7 +1242,8 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     if (!c) return DCP_EINVAL;
     c->rs_force_stg = stg;
     c->rs_force_bw = bw & 0xffu;
-    c->rs_pad_lds = (bw >> 8) * 1024u; // bits 8..: KiB of unused LDS per block (fewer blocks per CU)
+    c->rs_pad_lds = ((bw >> 8) & 0xffu) * 1024u; // bits 8..15: KiB of unused LDS per block (fewer blocks per CU)
+    c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
     return DCP_OK;
 }
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)

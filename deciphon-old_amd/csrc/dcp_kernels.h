@@ -170,7 +170,8 @@ unsigned dcp_rowsweep_tasks_per_block(int W);
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large
 int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,
-                             unsigned pad_lds); // pad_lds: unused dynamic LDS per block (occupancy experiments), normally 0
+                             unsigned pad_lds, // unused dynamic LDS per block (occupancy experiments), normally 0
+                             int prefetch2);   // != 0: the variant that fetches its global rows two DP rows ahead
 unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg); // 0: no kernel stages `stg` rows for this class
 unsigned dcp_rowsweep_stage_bytes(int R, int stg);
 int dcp_launch_qlane(dcp_qlane_args const *a, unsigned nblocks, unsigned nt, void *stream); // nt: 64, 128 or 256 queries per block

@@ -269,7 +269,7 @@ __device__ __forceinline__ void chain_rest(float const (&a)[R], float (&d)[R], f
 // cross-lane part of the row.
 template <int R, int W, int PH, class Fetch>
 __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
-                                         float (&em)[5][R], float (&eN)[5], float (&eI)[5],
+                                         float (&em)[5][R], float (&em3)[R], float (&em4)[R], float (&em5)[R], float (&eN)[5], float (&eI)[5],
                                          LaneSpecial const &sp, float const xEB,
                                          Exchange<(W > 1 ? W : 1)> *xc,
                                          unsigned wave, unsigned lane,
@@ -285,8 +285,8 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     for (int r = 0; r < R; ++r)
     {
         m[r] = max5(s.P[s1][r] + em[0][r], s.P[s2][r] + em[1][r],
-                    s.P[s3][r] + em[2][r], s.P[s4][r] + em[3][r],
-                    s.P[s5][r] + em[4][r]);
+                    s.P[s3][r] + em3[r], s.P[s4][r] + em4[r],
+                    s.P[s5][r] + em5[r]);
         ins[r] = max5(s.Q[s1][r] + eI[0], s.Q[s2][r] + eI[1], s.Q[s3][r] + eI[2],
                       s.Q[s4][r] + eI[3], s.Q[s5][r] + eI[4]);
     }
@@ -468,11 +468,14 @@ typedef char const __attribute__((address_space(1))) *gchar_ptr;
 // DP row's five reads go to -- sit in the block's LDS (`stg`, same [code][ldk] layout): they are the rows
 // every query of the profile keeps re-reading, and out of LDS they cost the L1 / L2 path nothing.
 typedef float const __attribute__((address_space(3))) *lds_cfloat_ptr;
-template <int R, int STAGED>
+// LMASK: bit l - 1 set = load the rows of the l-base word (the rows of three to five bases go to em3 / em4 / em5, which a
+// caller prefetching them two DP rows ahead points at the buffer of that row's parity); SCALARS: also the
+// insert / background emissions of the row.
+template <int R, int STAGED, int LMASK = 31, bool SCALARS = true>
 __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
                                          unsigned ldk, unsigned &lane_boff,
                                          cfloat *eN_tab, cfloat *eI_tab,
-                                         unsigned w, float (&em)[5][R],
+                                         unsigned w, float (&em)[5][R], float (&em3)[R], float (&em4)[R], float (&em5)[R],
                                          float (&eN)[5], float (&eI)[5], float const *stg)
 {
     asm volatile("" : "+v"(lane_boff));
@@ -480,22 +483,29 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
     for (int l = 1; l <= 5; ++l)
     {
         unsigned const c = code_of(w, l);
-        if (STAGED > 0 && (l == 1 ? 4 : l == 2 ? 20 : l == 3 ? 84 : 1364) <= STAGED) // the staged rows hold all words of l bases
+        if ((LMASK >> (l - 1)) & 1)
         {
-            // the row's byte offset as ONE scalar value (left alone, the constant part of a two-base word's
-            // row becomes a second per-lane add: ds_read2's offset fields are too narrow for it)
-            unsigned roff = c * ldk * 4u;
-            asm volatile("" : "+s"(roff));
-            VecLoad<R>::ld((float const *)((char const *)stg + (roff + lane_boff)), em[l - 1]);
+            float(&dst)[R] = l == 3 ? em3 : l == 4 ? em4 : l == 5 ? em5 : em[l - 1];
+            if (STAGED > 0 && (l == 1 ? 4 : l == 2 ? 20 : l == 3 ? 84 : 1364) <= STAGED) // the staged rows hold all words of l bases
+            {
+                // the row's byte offset as ONE scalar value (left alone, the constant part of a two-base word's
+                // row becomes a second per-lane add: ds_read2's offset fields are too narrow for it)
+                unsigned roff = c * ldk * 4u;
+                asm volatile("" : "+s"(roff));
+                VecLoad<R>::ld((float const *)((char const *)stg + (roff + lane_boff)), dst);
+            }
+            else
+            {
+                gchar_ptr row = (gchar_ptr)em_base + c * ldk * 4u; // < 2^32: 1364 codes x 4096 nodes x 4 B
+                asm volatile("" : "+s"(row));
+                VecLoad<R>::ld((float const *)(row + lane_boff), dst);
+            }
         }
-        else
+        if (SCALARS)
         {
-            gchar_ptr row = (gchar_ptr)em_base + c * ldk * 4u; // < 2^32: 1364 codes x 4096 nodes x 4 B
-            asm volatile("" : "+s"(row));
-            VecLoad<R>::ld((float const *)(row + lane_boff), em[l - 1]);
+            eN[l - 1] = eN_tab[c];
+            eI[l - 1] = eI_tab[c];
         }
-        eN[l - 1] = eN_tab[c];
-        eI[l - 1] = eI_tab[c];
     }
 }
 
@@ -519,12 +529,17 @@ constexpr int rs_min_waves(int R) { return R <= 4 ? 4 : 2; }
 // query-lane kernel could not finish, dcp_qlane.hip: a persistent grid strides over the list) or, without a
 // list, chunk `task % nchunks` of profile `task / nchunks`.
 constexpr int rs_block_threads(int R, int W, int STG) { return W > 1 ? 64 * W : STG > 0 ? (R <= 4 ? 1024 : 512) : 256; }
-template <int R, int W, int STG>
+// PF (staged variants): the rows that still come from global memory are fetched TWO DP rows ahead -- the variants of
+// the small batches, which wait for HBM latency (one query: a wavefront's row takes as long as its loads).
+template <int R, int W, int STG, bool PF>
 __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R)) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
+    static_assert(!PF || STG > 0, "only staged variants prefetch two rows ahead");
     static_assert(W == 1 || STG == 0, "only one-wavefront pairs stage rows");
     constexpr unsigned TASKS_PER_BLOCK = (W == 1 && STG == 0) ? 4u : 1u;
     constexpr int STAGED = STG;
+    constexpr bool PF2 = PF;
+    constexpr int NEAR = STG >= 84 ? 7 : 3, FAR = 31 - NEAR; // word lengths read from LDS / from global memory
     __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
     __shared__ __attribute__((aligned(16))) float stage_mem[STAGED > 0 ? STAGED * 64 * R : 4];
     float const *const stg = stage_mem;
@@ -650,19 +665,61 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R)) void 
         }
 
         float em[5][R], eN[5], eI[5];
-        unsigned w = base_at(words, 0);
-        unsigned lane_boff = lane_off * 4u; // pinned in place by load_row's asm (by value it is copied per row)
-        load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, eN, eI, stg);
         RowOut o{ni, ni};
         unsigned j = 1;
+        unsigned lane_boff = lane_off * 4u; // pinned in place by load_row's asm (by value it is copied per row)
+        if constexpr (PF2)
+        {
+            // The rows that still come from global memory (the four- and five-base words) are fetched TWO DP rows
+            // ahead into the buffer of that row's parity: a small batch streams them from HBM and is short of
+            // loads in flight, not of bytes (profiles/r03/rowsweep_variants.txt).  Rows are unrolled by ten (phase
+            // j % 5 x parity); the words past the last base are padding.
+            float emg[2][3][R]; // [parity][three-, four-, five-base rows] (the three-base slot is unused with 84 rows staged)
+            unsigned w1 = base_at(words, 0);                                   // window of row 1
+            unsigned w2 = ((w1 << 2) | base_at(words, 1)) & 1023u;              // window of row 2
+            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg);
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, emg[1][0], emg[1][1], emg[1][2], eN, eI, stg);
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[0][0], emg[0][1], emg[0][2], eN, eI, stg);
+#define DCP_E3(PAR) (STG >= 84 ? em[2] : emg[PAR][0])
+#define DCP_ROW2(PH, PAR)                                                      \
+    {                                                                          \
+        w1 = w2;                                               /* row j + 1 */ \
+        w2 = ((w2 << 2) | base_at(words, j + 1u)) & 1023u;     /* row j + 2 */ \
+        o = dp_row<R, W, PH>(s, t, em, DCP_E3(PAR), emg[PAR][1], emg[PAR][2], eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
+            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg); \
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[PAR][0], emg[PAR][1], emg[PAR][2], eN, eI, stg); \
+        });                                                                    \
+        ++j;                                                                   \
+    }
+            while (j + 9 <= L)
+            {
+                DCP_ROW2(1, 1) DCP_ROW2(2, 0) DCP_ROW2(3, 1) DCP_ROW2(4, 0) DCP_ROW2(0, 1)
+                DCP_ROW2(1, 0) DCP_ROW2(2, 1) DCP_ROW2(3, 0) DCP_ROW2(4, 1) DCP_ROW2(0, 0)
+            }
+            if (j <= L) DCP_ROW2(1, 1)
+            if (j <= L) DCP_ROW2(2, 0)
+            if (j <= L) DCP_ROW2(3, 1)
+            if (j <= L) DCP_ROW2(4, 0)
+            if (j <= L) DCP_ROW2(0, 1)
+            if (j <= L) DCP_ROW2(1, 0)
+            if (j <= L) DCP_ROW2(2, 1)
+            if (j <= L) DCP_ROW2(3, 0)
+            if (j <= L) DCP_ROW2(4, 1)
+#undef DCP_ROW2
+#undef DCP_E3
+        }
+        else
+        {
+        unsigned w = base_at(words, 0);
+        load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg);
 
 // compute row j from the tables in registers; once consumed they are refilled for row j+1
 // (the word one past the last base is padding: harmless)
 #define DCP_ROW(PH)                                                            \
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
-        o = dp_row<R, W, PH>(s, t, em, eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
-            load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, eN, eI, stg); \
+        o = dp_row<R, W, PH>(s, t, em, em[2], em[3], em[4], eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
+            load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg); \
         });                                                                    \
         ++j;                                                                   \
     }
@@ -674,6 +731,7 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R)) void 
         if (j <= L) DCP_ROW(2)
         if (j <= L) DCP_ROW(3)
         if (j <= L) DCP_ROW(4)
+        }
 #undef DCP_ROW
 
         // C(L) and R(L) sit in lanes 2 and 3
@@ -1229,11 +1287,11 @@ extern "C" void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles,
                        (hipStream_t)stream, *a);
 }
 
-template <int R, int W, int STG>
+template <int R, int W, int STG, bool PF = false>
 static void launch_rs(dcp_scan_args const *a, unsigned nblocks, unsigned threads, hipStream_t s, unsigned pad_lds = 0)
 {
     // pad_lds: unused dynamic LDS -- fewer blocks per CU (an occupancy experiment of the tests' build)
-    hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W, STG>), dim3(nblocks), dim3(threads), pad_lds, s, *a);
+    hipLaunchKernelGGL((viterbi_rowsweep_kernel<R, W, STG, PF>), dim3(nblocks), dim3(threads), pad_lds, s, *a);
 }
 
 // tasks per block of the unstaged (R, W) kernel: 4 independent wavefronts when W == 1
@@ -1254,7 +1312,7 @@ extern "C" unsigned dcp_rowsweep_stage_bytes(int R, int stg) { return (unsigned)
 //   stg  rows staged in LDS (0: every wavefront its own task, four per block);
 //   bw   wavefronts per staged block (1..dcp_rowsweep_max_block_waves).
 extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,
-                                        unsigned pad_lds)
+                                        unsigned pad_lds, int prefetch2)
 {
     hipStream_t s = (hipStream_t)stream;
     unsigned const maxw = dcp_rowsweep_max_block_waves(R, W, stg);
@@ -1273,7 +1331,8 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
 #define DCP_CASE_S(r, g)                                                       \
     if (R == r && W == 1 && stg == g)                                          \
     {                                                                          \
-        launch_rs<r, 1, g>(a, nblocks, 64u * bw, s, pad_lds);                  \
+        if (prefetch2) launch_rs<r, 1, g, true>(a, nblocks, 64u * bw, s, pad_lds); \
+        else launch_rs<r, 1, g, false>(a, nblocks, 64u * bw, s, pad_lds);      \
         return 0;                                                              \
     }
     DCP_CASE_S(1, 20) DCP_CASE_S(2, 20) DCP_CASE_S(3, 20) DCP_CASE_S(4, 20) DCP_CASE_S(5, 20) DCP_CASE_S(6, 20)
