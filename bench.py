@@ -437,12 +437,18 @@ def main():
     if (world > 1 or force_dist) and args.hit_gather == "c":
         idt = torch.zeros(ddist.ID_BYTES, dtype=torch.uint8, device="cuda")
         why = ""
-        if rank == 0:
-            try:
-                idt.copy_(torch.frombuffer(bytearray(ddist.CDist.unique_id()), dtype=torch.uint8))
-            except Exception as ex:  # librccl not loadable: every rank sees the all-zero id
-                why = str(ex)
-        dist.broadcast(idt, 0)
+        # every rank first proves it can load librccl and get an id of its own: a rank that could not would never
+        # enter ncclCommInitRank, and the others would wait there for ever
+        my_id = None
+        try:
+            my_id = ddist.CDist.unique_id()
+        except Exception as ex:
+            why = str(ex)
+        can = torch.tensor([1 if my_id else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if int(can.item()) == 1 and rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+        dist.broadcast(idt, 0)  # all zero when some rank cannot load librccl
         id_bytes = bytes(idt.cpu().numpy().tobytes())
         if any(id_bytes):
             try:
@@ -564,6 +570,36 @@ def main():
                        "scan of the whole resident DB shard -> hit records on the host"
                        + (" through the hit gather" if (world > 1 or force_dist) else " (D2H)")
                        + "; the batches are those of the first timed steps of the resident leg"}
+    # ---- small batches (N = 1 only): what the reference's own loop sees -- it scans ONE sequence at a time
+    # (src/server/scan.c:227-258) -- and batches of 8 and 64: upload + scan of the whole DB + hits on the host per
+    # batch, automatic kernel choice (the row sweep at these sizes), median of three; outside every timed region
+    small = None
+    if world == 1 and not force_dist and not args.dense and not args.stub_scan and args.kernel == "auto":
+        small = {}
+        src = e2e_batches[0] if n_e2e else queries[:qstep]
+        for nq_small in (1, 8, 64):
+            if nq_small > len(src):
+                continue
+            batch = src[:nq_small]
+            ts = []
+            for _rep in range(4):
+                t0 = time.perf_counter()
+                if qlen:
+                    sc.upload_seqs_flat(np.ascontiguousarray(batch).reshape(-1),
+                                        (np.arange(nq_small + 1, dtype=np.uint64) * qlen).astype(np.uint32))
+                else:
+                    sc.upload_seqs(batch)
+                sc.scan(True, False, 10.0, keep_scores=False, sync=True, kernel=dcp.KERNEL_AUTO)
+                nh = min(cap, int(hit_count.item()))
+                _ = hit_words[:nh].cpu().numpy()
+                ts.append(time.perf_counter() - t0)
+            t_med = sorted(ts[1:])[1]
+            cells_small = float(sizes[b:e].sum()) * float(sum(len(x) for x in batch))
+            small[str(nq_small)] = {"ms": round(t_med * 1e3, 2), "kernel_ms": round(sc.last_scan_ms, 2),
+                                    "seqs_per_sec": round(nq_small / t_med, 1),
+                                    "gcells_per_s": round(cells_small / t_med / 1e9, 1)}
+        small["what"] = ("per batch: host sequences -> upload -> scan of the whole resident DB (automatic kernel choice: "
+                         "the row sweep at these sizes) -> hit records on the host; median of 3 after one untimed pass")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -714,6 +750,7 @@ def main():
             },
             "roofline": roof,
             "e2e": e2e,
+            "small_batches": small,
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
             # every DCP_* variable in the environment (the library reads none of them; bench.py reads
             # DCP_BENCH_FORCE_DIST only)
