@@ -858,7 +858,7 @@ static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunk
     if (nchunks >= 6u && nchunks <= 36u && max84 != 0u)
     {
         unsigned const w84 = balanced(max84);
-        unsigned const slots = R <= 4 ? 16u : 8u; // wavefronts of this class a CU runs at the kernel's register count
+        unsigned const slots = dcp_rowsweep_max_block_waves(R, W, 84); // wavefronts of this class a CU runs at the kernel's register count
         unsigned const blocks = (160u * 1024u) / dcp_rowsweep_stage_bytes(R, 84);
         // the image may cost up to half of them: such a batch waits for HBM, not for issue slots (8 queries with
         // the R = 4 class at 8 of 16 wavefronts per CU: 49 ms; with that class on the 20-row image: 51)
