@@ -605,11 +605,14 @@ def test_positive_delete_transitions_keep_d_in_e(dcp, oracle32, scanner, kern, m
     assert np.isfinite(oa).all()
 
 
-@pytest.mark.parametrize("stage,waves", [(0, 4), (20, 1), (20, 3), (20, 4), (20, 16), (84, 1), (84, 5), (84, 8), (84, 16)])
-def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves):
+@pytest.mark.parametrize("stage,waves,prefetch2", [(0, 4, 0), (20, 1, 0), (20, 3, 0), (20, 4, 0), (20, 16, 0), (84, 1, 0),
+                                                  (84, 5, 0), (84, 8, 0), (84, 16, 0), (20, 1, 1), (20, 3, 1), (20, 16, 1),
+                                                  (84, 1, 1), (84, 5, 1), (84, 16, 1)])
+def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves, prefetch2):
     """Every grid-mode variant of the row sweep -- rows of the emission table a block keeps in LDS (none, the
     one- and two-base words, the three-base words as well) x wavefronts per block (one profile per block: blocks
-    with spare wavefronts, a last block that is not full, more chunks than one block takes) -- against the
+    with spare wavefronts, a last block that is not full, more chunks than one block takes) x global rows fetched one
+    or two DP rows ahead (sequences of 1..150 nt: every length of the ten-row unrolling's tail) -- against the
     oracle's float32 recursion on the product's tables, bit for bit, over every one-wavefront size class, a
     flagged (positive MD / DD) profile and multi-wavefront classes (which have one variant).  Forced through the
     tests' own -DDCP_TEST_HOOKS build; the shipped library picks among the same kernels by batch size."""
@@ -627,15 +630,17 @@ def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves)
         prof_eps[id(pr)] = cfg.epsilon
     hooks_scanner.upload_db(profiles, expand_on_host=True)
     try:
-        hooks_scanner.test_set_rowsweep_variant(stage, waves)
+        hooks_scanner.test_set_rowsweep_variant(stage, waves | (prefetch2 << 16))
         for nseq in (1, 3, 21):
-            seqs = rand_seqs(rng, nseq, 1, 150)
+            # 21 sequences: lengths 1..21 (every tail of the five- and ten-row unrollings); else random up to 150 nt
+            seqs = ([rng.integers(0, 4, L, dtype=np.uint8) for L in range(1, 22)] if nseq == 21
+                    else rand_seqs(rng, nseq, 1, 150))
             hooks_scanner.upload_seqs(seqs)
             for multi in (True, False):
                 hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
                 gn, ga = hooks_scanner.scores()
                 on, oa = oracle_dp_on_product_tables(dcp, oracle32, hooks_scanner, profiles, seqs, multi, False, True)
-                assert same_bits(gn, on) and same_bits(ga, oa), (stage, waves, nseq, multi)
+                assert same_bits(gn, on) and same_bits(ga, oa), (stage, waves, prefetch2, nseq, multi)
     finally:
         hooks_scanner.test_set_rowsweep_variant(-1, 0)
 
