@@ -420,6 +420,7 @@ def main():
     e2e_batches = [queries[i * qstep:(i + 1) * qstep] for i in range(args.warmup, args.warmup + n_e2e)]
     if qlen:
         e2e_batches = [np.ascontiguousarray(x) for x in e2e_batches]
+    small_src = queries[:min(64, qstep)].copy() if qlen else list(queries[:min(64, qstep)])  # the small-batch leg's queries
     del queries
 
     cap = 1 << 16
@@ -576,7 +577,7 @@ def main():
     small = None
     if world == 1 and not force_dist and not args.dense and not args.stub_scan and args.kernel == "auto":
         small = {}
-        src = e2e_batches[0] if n_e2e else queries[:qstep]
+        src = small_src
         for nq_small in (1, 8, 64):
             if nq_small > len(src):
                 continue

@@ -744,6 +744,16 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
             ring_fetch<(FIRST || IN != IO_HBM)>(ring, (r + 1) % 5, pB, pXm, pXd, pEm, off + (unsigned)r * rowstep * 4u);
     }
 
+// timing build (bit 3): the scratch planes wrap after DCP_QLANE_DIAG_ROWS rows -- a block's planes then are
+// DCP_QLANE_DIAG_ROWS x 3 KB instead of (L + 8) x 3 KB: what keeping them in the L2 / Infinity Cache would buy
+#if DCP_QLANE_DIAG & 8
+#ifndef DCP_QLANE_DIAG_ROWS
+#define DCP_QLANE_DIAG_ROWS 256u
+#endif
+#define QL_DIAG8_WRAP off &= (DCP_QLANE_DIAG_ROWS * (unsigned)NT * 4u - 1u);
+#else
+#define QL_DIAG8_WRAP
+#endif
 #if DCP_QLANE_DIAG & 4
 #define QL_DIAG4_ARGS , off2, din
 #define QL_DIAG4_STEP off2 += rowstep_out * 4u;
@@ -784,6 +794,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         }                                                                                        \
         }                                                                                        \
         off += rowstep * 4u;                                                                     \
+        QL_DIAG8_WRAP                                                                            \
         QL_DIAG4_STEP                                                                            \
         ++j;                                                                               \
         /* keep the scheduler from pulling the next row's loads up here: the only   */     \
