@@ -117,6 +117,7 @@ struct dcp_gpu_ctx
     unsigned rs_force_bw = 0;
     unsigned rs_pad_lds = 0;
     int rs_force_pf = 0;
+    int rs_force_R = 0; // 0: every class
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
@@ -853,7 +854,7 @@ static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunk
         return (nchunks + nb - 1u) / nb;
     };
     int g = 20;
-    unsigned w = balanced(nchunks <= 80u ? 8u : 4u);
+    unsigned w = balanced(nchunks <= 56u ? 8u : 4u); // 48 queries: 198 ms with 8 wavefronts per block, 205 with 4; 64: 256 / 252
     unsigned const max84 = dcp_rowsweep_max_block_waves(R, W, 84);
     if (nchunks >= 6u && nchunks <= 36u && max84 != 0u)
     {
@@ -864,7 +865,9 @@ static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunk
         // the R = 4 class at 8 of 16 wavefronts per CU: 49 ms; with that class on the 20-row image: 51)
         if (std::min(blocks * w84, slots) * 2u >= slots) g = 84, w = w84;
     }
-    if (c->rs_force_stg >= 0 && dcp_rowsweep_max_block_waves(R, W, c->rs_force_stg) != 0u)
+    bool const forced = c->rs_force_stg >= 0 && (c->rs_force_R == 0 || c->rs_force_R == R) &&
+                        dcp_rowsweep_max_block_waves(R, W, c->rs_force_stg) != 0u;
+    if (forced)
     {
         g = c->rs_force_stg;
         w = g == 0 ? 4u : std::min(std::min(c->rs_force_bw ? c->rs_force_bw : 4u, dcp_rowsweep_max_block_waves(R, W, g)), nchunks);
@@ -872,7 +875,7 @@ static void rowsweep_variant(dcp_gpu_ctx const *c, int R, int W, unsigned nchunk
     *stg = g, *bw = std::max(1u, w);
     // two rows of prefetch: the batches that wait for HBM (the 84-row variants' range, and below it)
     *pf = g > 0 && nchunks <= 36u;
-    if (c->rs_force_stg >= 0 && g > 0) *pf = c->rs_force_pf;
+    if (forced && g > 0) *pf = c->rs_force_pf;
 }
 
 int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsigned q_begin,
@@ -1244,6 +1247,7 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     c->rs_force_bw = bw & 0xffu;
     c->rs_pad_lds = ((bw >> 8) & 0xffu) * 1024u; // bits 8..15: KiB of unused LDS per block (fewer blocks per CU)
     c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
+    c->rs_force_R = (int)((bw >> 20) & 15u);      // bits 20..23: only the class with this many nodes per lane (0: all)
     return DCP_OK;
 }
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)

@@ -23,7 +23,7 @@ off = (np.arange(nmax + 1, dtype=np.uint64) * 1000).astype(np.uint32)
 sc.upload_seqs_flat(q.reshape(-1), off)
 cellsM = int(sizes.sum())
 for var in variants or [None]:
-    if var: sc.test_set_rowsweep_variant(var[0], var[1] | ((var[2] if len(var) > 2 else 0) << 8) | ((var[3] if len(var) > 3 else 0) << 16))  # stage : waves [: KiB of LDS padding [: two-row prefetch]]
+    if var: sc.test_set_rowsweep_variant(var[0], var[1] | ((var[2] if len(var) > 2 else 0) << 8) | ((var[3] if len(var) > 3 else 0) << 16) | ((var[4] if len(var) > 4 else 0) << 20))  # stage : waves [: KiB of LDS padding [: two-row prefetch [: only class R]]]
     out = []
     for nq in nqs:
         for rep in range(3):
