@@ -388,10 +388,17 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     else
     {
         float published = ni; // lane 63: the D value the next wave last saw
+        // this wavefront's part of E(j): the match states' maximum, once per row (as for W == 1: the delete
+        // states cannot decide it unless the profile is flagged, and then they are added in every pass)
+        float e_m = m[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            e_m = fmaxf(e_m, m[r]);
+        e_m = wave_max(e_m);
         for (unsigned it = 0;; ++it, ++gen)
         {
             unsigned const buf = gen & 1u;
-            float const e_wave = wave_max(lane_max());
+            float const e_wave = exact_e ? wave_max(lane_max()) : e_m;
             if (lane == 63)
             {
                 if (it == 0)
