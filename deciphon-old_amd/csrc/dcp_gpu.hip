@@ -40,7 +40,7 @@ constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}
 // cells/s of each class on a full grid, measured on the C3 DB (profiles/r03/rowsweep_variants.txt; round 2:
 // profiles/r02/rowsweep_tuning.txt): the kernel choice prices a row-sweep scan with them
 constexpr double kClassRate[] = {600e9, 850e9, 1040e9, 1180e9, 1030e9, 1120e9, 1190e9, 1215e9,
-                                 480e9, 625e9, 425e9, 530e9, 400e9, 400e9};
+                                 660e9, 640e9, 750e9, 550e9, 600e9, 400e9}; // R = 3 multi-wavefront classes: the segmented sweep
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
 static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
 static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
@@ -158,12 +158,19 @@ struct dcp_gpu_ctx
     unsigned *ext_nhits = nullptr;
     unsigned ext_cap = 0;
     // one HIP event after each size-class launch of the last scan
-    hipEvent_t ev_class[kNumClasses + 1] = {nullptr};
+    static constexpr int kMaxLaunches = 2 * kNumClasses + 1; // a segmented class is two launches
+    hipEvent_t ev_class[kMaxLaunches] = {nullptr};
     // small row-sweep scans (the reference's one-sequence-at-a-time mode) are bound by the latency
     // of one pair's row chain, not by throughput: their size-class launches run side by side
     hipStream_t class_stream[kNumClasses] = {nullptr};
     bool last_overlapped = false;
-    int launched_class[kNumClasses + 1] = {0};
+    int launched_class[kMaxLaunches] = {0};
+    bool launched_redo[kMaxLaunches] = {false}; // the exact kernel behind a segmented sweep: its cells are counted there
+    // segmented sweep of the multi-wavefront classes (grid mode): per-class scratch columns and redo lists
+    DevBuf<float> d_seg_scratch;
+    DevBuf<dcp_pair> d_seg_redo;
+    DevBuf<unsigned> d_seg_redo_n; // [DCP_MAX_CLASSES]
+    int seg_mode = -1;             // test hook: 0 never, 1 always where a kernel exists, -1 automatic
     unsigned n_launched = 0;
 
     int fail(int rc, char const *fmt, ...)
@@ -229,7 +236,7 @@ dcp_gpu_ctx *dcp_gpu_ctx_new(int device)
         c->ql_G = (int)dcp_qlane_tile_nodes() / 4;
     }
     bool ok = true;
-    for (int k = 0; k <= kNumClasses; ++k)
+    for (int k = 0; k < dcp_gpu_ctx::kMaxLaunches; ++k)
         ok = ok && hipEventCreate(&c->ev_class[k]) == hipSuccess;
     for (int k = 0; k < kNumClasses; ++k)
         ok = ok && hipStreamCreateWithFlags(&c->class_stream[k], hipStreamNonBlocking) == hipSuccess;
@@ -251,7 +258,7 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (c->h_qstage) (void)hipHostFree(c->h_qstage);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    for (int k = 0; k <= kNumClasses; ++k)
+    for (int k = 0; k < dcp_gpu_ctx::kMaxLaunches; ++k)
         if (c->ev_class[k]) (void)hipEventDestroy(c->ev_class[k]);
     for (int k = 0; k < kNumClasses; ++k)
         if (c->class_stream[k]) (void)hipStreamDestroy(c->class_stream[k]);
@@ -1188,6 +1195,41 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     // fork / join around the class launches when no single one fills the chip
     bool const overlap = (uint64_t)nq * c->nprof < ((uint64_t)1 << 21);
     c->last_overlapped = overlap;
+    // Multi-wavefront classes with a segmented-sweep kernel (dcp_kernels.hip): one wavefront per pair over the
+    // profile's segments with B(j) = N(j) + NB, the pairs with feedback finished by the exact kernel behind it.
+    // Per class: scratch columns for the persistent grid's wavefronts and a redo list of all its pairs.
+    unsigned lmax_scan = 0;
+    for (unsigned q = q_begin; q < q_end; ++q)
+        lmax_scan = std::max(lmax_scan, c->seq_len[q]);
+    unsigned const seg_stride = 2u * (lmax_scan + 2u); // float4 per wavefront: two columns of lmax + 2 rows
+    unsigned seg_blocks[kNumClasses] = {0};
+    uint64_t seg_scr_off[kNumClasses] = {0}, seg_redo_off[kNumClasses] = {0}, seg_scr_tot = 0, seg_redo_tot = 0;
+    for (int k = 0; k < kNumClasses; ++k)
+    {
+        unsigned const np = c->class_first[k + 1] - c->class_first[k];
+        SizeClass const sc = kClasses[k];
+        uint64_t const pairs = (uint64_t)np * nq;
+        // (from about 32 queries on: below, a pair's segments one after the other are a longer serial chain than the
+        // exact kernel's wavefronts side by side -- 1 query 11.8 -> 14.4 ms, 16 queries 79 -> 81, 64: 252 -> 247)
+        bool const want = c->seg_mode == 1 || (c->seg_mode < 0 && nq >= 32u);
+        bool const have = sc.W > 1 && sc.R == 3 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
+        if (!have) continue;
+        uint64_t nb = std::min<uint64_t>((pairs + 3u) / 4u, 2ull * c->num_cus); // 2 wavefronts per SIMD
+        nb = (nb + 7u) / 8u * 8u;
+        uint64_t const scr = nb * 4u * seg_stride * 4u; // floats
+        if ((seg_scr_tot + scr) * sizeof(float) > ((uint64_t)8 << 30)) continue; // very long sequences: the exact kernel
+        seg_blocks[k] = (unsigned)nb;
+        seg_scr_off[k] = seg_scr_tot, seg_scr_tot += scr;
+        seg_redo_off[k] = seg_redo_tot, seg_redo_tot += pairs;
+    }
+    if (seg_scr_tot)
+    {
+        if (c->d_seg_scratch.n < seg_scr_tot) HIP_TRY(c, c->d_seg_scratch.alloc((size_t)seg_scr_tot));
+        if (c->d_seg_redo.n < seg_redo_tot) HIP_TRY(c, c->d_seg_redo.alloc((size_t)seg_redo_tot));
+        if (!c->d_seg_redo_n.p) HIP_TRY(c, c->d_seg_redo_n.alloc(DCP_MAX_CLASSES));
+        HIP_TRY(c, hipMemsetAsync(c->d_seg_redo_n.p, 0, DCP_MAX_CLASSES * sizeof(unsigned), c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_start, c->stream)); // the forked streams wait for the counters' reset too
+    }
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
@@ -1196,9 +1238,37 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         if (overlap) HIP_TRY(c, hipStreamWaitEvent(ls, c->ev_start, 0));
         a.first_prof = first;
         a.nprof = last - first;
+        a.pairs = nullptr, a.npairs = nullptr, a.pair_cap = 0;
         SizeClass const sc = kClasses[k];
         uint64_t const ntasks = (uint64_t)a.nprof * a.nchunks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
+        if (seg_blocks[k])
+        {
+            a.seg_scratch = c->d_seg_scratch.p + seg_scr_off[k];
+            a.seg_stride = seg_stride;
+            a.seg_redo = c->d_seg_redo.p + seg_redo_off[k];
+            a.seg_redo_n = c->d_seg_redo_n.p + k;
+            a.seg_redo_cap = (unsigned)ntasks;
+            if (dcp_launch_segsweep(sc.R, sc.W, &a, seg_blocks[k], ls))
+                return c->fail(DCP_EFAIL, "no segmented kernel for class R=%d W=%d", sc.R, sc.W);
+            HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
+            c->launched_redo[c->n_launched] = false;
+            c->launched_class[c->n_launched++] = k;
+            c->last_launches++;
+            // the pairs it could not finish: the exact kernel in pair mode, right behind
+            a.pairs = a.seg_redo, a.npairs = a.seg_redo_n, a.pair_cap = a.seg_redo_cap;
+            a.first_prof = 0, a.nprof = c->nprof;
+            uint64_t g = std::min<uint64_t>(ntasks, 8ull * c->num_cus);
+            g = (g + 7u) / 8u * 8u;
+            if (dcp_launch_rowsweep(sc.R, sc.W, &a, (unsigned)g, ls))
+                return c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
+            HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
+            if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_class[c->n_launched], 0));
+            c->launched_redo[c->n_launched] = true;
+            c->launched_class[c->n_launched++] = k;
+            c->last_launches++;
+            continue;
+        }
         int stg, pf;
         unsigned bw;
         rowsweep_variant(c, sc.R, sc.W, a.nchunks, &stg, &bw, &pf);
@@ -1207,6 +1277,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                              : c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d (stage %d, %u wavefronts)", sc.R, sc.W, stg, bw);
         HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
         if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_class[c->n_launched], 0));
+        c->launched_redo[c->n_launched] = false;
         c->launched_class[c->n_launched++] = k;
         c->last_launches++;
     }
@@ -1248,6 +1319,7 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     c->rs_pad_lds = ((bw >> 8) & 0xffu) * 1024u; // bits 8..15: KiB of unused LDS per block (fewer blocks per CU)
     c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
     c->rs_force_R = (int)((bw >> 20) & 15u);      // bits 20..23: only the class with this many nodes per lane (0: all)
+    c->seg_mode = ((bw >> 24) & 3u) == 1u ? 0 : ((bw >> 24) & 3u) == 2u ? 1 : -1; // bits 24..25: 1 = never the segmented sweep, 2 = always
     return DCP_OK;
 }
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)
@@ -1307,7 +1379,7 @@ int dcp_gpu_last_scan_launch_info(dcp_gpu_ctx *c, unsigned i, struct dcp_launch_
         out->algorithmic_bytes = dcp_gpu_scan_algorithmic_bytes(c);
         return DCP_OK;
     }
-    if (c->last_kernel == 2) // a redo launch: its pairs are counted in the query-lane launch
+    if (c->last_kernel == 2 || c->launched_redo[i]) // a redo launch: its pairs are counted in the launch before it
     {
         out->nodes_per_lane = kClasses[k].R;
         out->waves_per_pair = kClasses[k].W;

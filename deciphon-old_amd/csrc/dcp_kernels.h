@@ -57,6 +57,13 @@ struct dcp_scan_args
     dcp_pair const *pairs;
     unsigned const *npairs;
     unsigned pair_cap;
+    // segmented sweep of a multi-wavefront class (viterbi_segsweep_kernel): per-wavefront scratch columns of
+    // seg_stride float4 (two halves of lmax + 2 rows), and the list of the pairs it hands to the exact kernel
+    float *seg_scratch;
+    unsigned seg_stride;
+    dcp_pair *seg_redo;
+    unsigned *seg_redo_n;
+    unsigned seg_redo_cap;
 };
 
 // One 64-column tile of the expansion kernel.
@@ -167,6 +174,8 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
+// one wavefront per pair over the segments of a profile of a multi-wavefront class; != 0: no such kernel
+int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large
 int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,

@@ -454,6 +454,94 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
     return RowOut{E, X};
 }
 
+// ---- segmented sweep (profiles of more than 512 nodes, one wavefront per pair) ------------------------------------
+// One DP row of ONE SEGMENT of 64 x R consecutive nodes.  The wavefront sweeps the segments of a profile one after
+// the other over all rows, the way the query-lane kernels sweep tiles: what row j of the next segment needs from
+// this one -- M, I, D of the segment's last node and the running E -- goes through a per-wavefront scratch column
+// (16 bytes per row), and B(j) is taken as N(j) + NB only; the last segment, which has the final E(j) and J(j),
+// checks whether max(E(j) + EB, J(j) + JB) ever exceeded it.  If never, N + NB IS B (a forward recurrence has one
+// solution) and the scores are exactly the multi-wavefront kernel's; a pair where it did goes to that kernel
+// through a redo list.  `bin`: this row's boundary values from the previous segment (m, i, d of its last node, E so
+// far; -inf for the first segment); `bout`: where lane 63 puts this segment's.
+struct SegBnd
+{
+    float m, i, d, e;
+};
+template <int R, int PH, bool LASTSEG, class Fetch>
+__device__ __forceinline__ RowOut seg_row(PairState<R> &s, Trans<R> const &t, float (&em)[5][R], float (&eN)[5],
+                                          float (&eI)[5], LaneSpecial const &sp, float const cJ, float const xEB,
+                                          SegBnd const &bin, float4 *bout, unsigned lane, bool &dirty, Fetch &&fetch)
+{
+    constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5, s4 = (PH + 1) % 5, s5 = PH;
+    float m[R], ins[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+    {
+        m[r] = max5(s.P[s1][r] + em[0][r], s.P[s2][r] + em[1][r], s.P[s3][r] + em[2][r], s.P[s4][r] + em[3][r],
+                    s.P[s5][r] + em[4][r]);
+        ins[r] = max5(s.Q[s1][r] + eI[0], s.Q[s2][r] + eI[1], s.Q[s3][r] + eI[2], s.Q[s4][r] + eI[3],
+                      s.Q[s5][r] + eI[4]);
+    }
+    float const X = max5(s.PX[s1] + eN[0], s.PX[s2] + eN[1], s.PX[s3] + eN[2], s.PX[s4] + eN[3], s.PX[s5] + eN[4]);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // E(j) so far: the previous segments' and this one's match states (flagged profiles never come here)
+    float em_ = m[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        em_ = fmaxf(em_, m[r]);
+    float const E = fmaxf(bin.e, wave_max(em_));
+
+    // delete chain: lane 0 continues the previous segment's chain (its D is final there)
+    float a[R], d[R];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        a[r] = m[r - 1] + t.md[r];
+    // (lane 0: max(M_prev + MD, D_prev + DD), both final; the other lanes' D(lane - 1) comes with the passes below)
+    {
+        float const first_only = shr1_add<true>(m[R - 1], bin.m, t.md[0]);
+        d[0] = lane == 0u ? fmaxf(first_only, bin.d + t.dd[0]) : first_only;
+    }
+    chain_rest<R>(a, d, t.dd);
+    for (;;)
+    {
+        float const c0 = shr1_add<true>(d[R - 1], bin.d, t.dd[0]);
+        unsigned long long changed;
+        asm("v_cmp_gt_f32_e64 %0, %2, %1\n\t"
+            "v_max_f32_e32 %1, %1, %2"
+            : "=&s"(changed), "+v"(d[0])
+            : "v"(c0));
+        if (changed == 0ull) break;
+        chain_rest<R>(a, d, t.dd);
+    }
+
+    // what the next segment needs from this row
+    if constexpr (!LASTSEG)
+        if (lane == 63u) *bout = float4{m[R - 1], ins[R - 1], d[R - 1], E};
+
+    // B(j) as this sweep takes it: N(j) + NB (lanes t & 3 = 0 hold N; cJ keeps J out)
+    float const B = quad_max(X + sp.c);
+    if constexpr (LASTSEG)
+    {
+        // did E(j) -> B(j) or J(j) -> B(j) beat it?  (X + cJ: J + JB in the lanes that hold J, -inf elsewhere)
+        float const B1 = fmaxf(quad_max(X + cJ), E + xEB);
+        dirty = dirty || B1 > B;
+    }
+    s.P[PH][0] = fmaxf(fmaxf(B + t.ent[0], shr1_add<true>(m[R - 1], bin.m, t.mm[0])),
+                       fmaxf(shr1_add<true>(ins[R - 1], bin.i, t.im[0]), shr1_add<true>(d[R - 1], bin.d, t.dm[0])));
+    s.Q[PH][0] = fmaxf(m[0] + t.mi[0], ins[0] + t.ii[0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+    {
+        s.P[PH][r] = fmaxf(fmaxf(B + t.ent[r], m[r - 1] + t.mm[r]), fmaxf(ins[r - 1] + t.im[r], d[r - 1] + t.dm[r]));
+        s.Q[PH][r] = fmaxf(m[r] + t.mi[r], ins[r] + t.ii[r]);
+    }
+    s.PX[PH] = fmaxf(E + sp.a, X + sp.b);
+    return RowOut{E, X};
+}
+
 // base `pos` of the sequence (a scalar load: the address is wave-uniform)
 __device__ __forceinline__ unsigned base_at(cu32 *words, unsigned pos)
 {
@@ -764,6 +852,164 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R, W)) vo
         }
     }
     if (!pair_mode) break; // grid mode: one task per block
+    }
+}
+
+// ============================================================================
+// Segmented sweep: one wavefront per (profile, query) pair of a multi-wavefront size class, the profile cut into
+// segments of 64 x R nodes that the wavefront sweeps one after the other (seg_row above).  Grid mode only; a
+// persistent grid strides over the class's profiles x queries.  Pairs with E -> B / J -> B feedback, and all pairs
+// of a profile flagged DCP_PROF_EXACT_E, are appended to `seg_redo` for the exact kernel (pair mode), which runs
+// right behind on the same stream.  Each wavefront owns a scratch column of 2 x (lmax + 2) rows of 16 bytes.
+// ============================================================================
+template <int R>
+__global__ __launch_bounds__(256, 2) void viterbi_segsweep_kernel(dcp_scan_args a)
+{
+    unsigned const lane = threadIdx.x & 63u;
+    unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned const nblk = gridDim.x; // multiple of 8
+    unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    unsigned const gwave = vblk * 4u + wave;
+    unsigned const ntasks = a.nprof * a.nseqs;
+    float4 *const scr = reinterpret_cast<float4 *>(a.seg_scratch) + (size_t)gwave * a.seg_stride; // [2][seg_stride / 2]
+    unsigned const half = a.seg_stride >> 1;
+    float const ni = neg_inf();
+    for (unsigned task = gwave; task < ntasks; task += nblk * 4u)
+    {
+        unsigned const s_rel = task / a.nseqs;
+        unsigned const slot = __builtin_amdgcn_readfirstlane(a.first_prof + s_rel);
+        unsigned const q = __builtin_amdgcn_readfirstlane(task - s_rel * a.nseqs);
+        dcp_prof_meta const pm = a.profs[slot];
+        unsigned const ldk = pm.ldk; // the class capacity: a multiple of 64 x R
+        unsigned const nseg = (pm.core_size + 64u * R - 1u) / (64u * R);
+        bool dirty = (pm.flags & DCP_PROF_EXACT_E) != 0u;
+        float const *__restrict__ em_prof = a.emis_match + pm.emis_off;
+        cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
+        cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
+        unsigned const L = a.seq_len[q];
+        cu32 *words = as_const(a.seq_words + a.seq_woff[q]);
+        cfloat *xt = as_const(a.xtrans + (size_t)q * DCP_XSTRIDE);
+        unsigned const x = lane & 3u; // this lane's special state: 0 N, 1 J, 2 C, 3 R
+        LaneSpecial sp;
+        sp.a = x == 1u ? xt[DCP_X_EJ] : x == 2u ? xt[DCP_X_EC] : ni;
+        sp.b = x == 0u ? xt[DCP_X_NN] : x == 1u ? xt[DCP_X_JJ] : x == 2u ? xt[DCP_X_CC] : xt[DCP_X_RR];
+        sp.c = x == 0u ? xt[DCP_X_NB] : ni;          // B(j) as swept: N(j) + NB
+        float const cJ = x == 1u ? xt[DCP_X_JB] : ni; // the J -> B candidate, checked in the last segment
+        float xEB = xt[DCP_X_EB];
+        asm volatile("" : "+v"(xEB));
+        RowOut o{ni, ni};
+        for (unsigned seg = 0; seg < nseg && !dirty; ++seg) // `dirty` is wave-uniform
+        {
+            bool const last = seg + 1u == nseg;
+            unsigned const lane_off = seg * 64u * R + lane * R;
+            float const *__restrict__ em_base = em_prof; // wave-uniform; the lane's columns through lane_boff
+            Trans<R> t;
+            {
+                float const *__restrict__ tb = a.trans8 + pm.trans_off + lane_off;
+                VecLoad<R>::ld(tb + (size_t)DCP_T_ENTRY * ldk, t.ent);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_MM * ldk, t.mm);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_IM * ldk, t.im);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_DM * ldk, t.dm);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_MD * ldk, t.md);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_DD * ldk, t.dd);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_MI * ldk, t.mi);
+                VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
+            }
+            // The previous segment's boundary column is read with SCALAR loads (the row's values are wave-uniform and
+            // only lane 0 needs them as operands): they count on lgkmcnt with the row's other scalar loads, so waiting
+            // for them never drains the emission rows in flight (as vector loads, a copy of the just-loaded values at
+            // the end of every row did: vmcnt(0)).  The column was written by this wavefront's vector stores: they are
+            // complete (in this XCD's L2, which the scalar cache reads from) after a workgroup-scope release fence --
+            // s_waitcnt vmcnt(0); an agent-scope one would write the whole L2 back (buffer_wbl2), twice per pair --
+            // and the scalar cache drops what it may hold of an earlier use of the scratch.
+            cfloat *bsrc = as_const(reinterpret_cast<float const *>(scr + (seg & 1u ? 0u : half))); // what s - 1 wrote
+            float4 *bdst = scr + (seg & 1u ? half : 0u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_dcache_inv();
+            PairState<R> s;
+#pragma unroll
+            for (int h = 0; h < 5; ++h)
+            {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    s.P[h][r] = ni, s.Q[h][r] = ni;
+                s.PX[h] = ni;
+            }
+            {
+                float const B0 = 0.0f + xt[DCP_X_SB];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    s.P[0][r] = B0 + t.ent[r];
+                s.PX[0] = x == 0u ? 0.0f + xt[DCP_X_SN] : x == 3u ? 0.0f : ni;
+            }
+            float em[5][R], eN[5], eI[5];
+            unsigned w = base_at(words, 0);
+            unsigned lane_boff = lane_off * 4u;
+            load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr);
+            SegBnd bnd{ni, ni, ni, ni}, bnx{ni, ni, ni, ni};
+            if (seg > 0u) bnd = SegBnd{bsrc[4], bsrc[5], bsrc[6], bsrc[7]}; // row 1
+            unsigned j = 1;
+            bool seg_dirty = false;
+#define DCP_SROW(PH, LASTSEG)                                                                      \
+    {                                                                                             \
+        w = ((w << 2) | base_at(words, j)) & 1023u;                                               \
+        o = seg_row<R, PH, LASTSEG>(s, t, em, eN, eI, sp, cJ, xEB, bnd, bdst + j, lane, seg_dirty, [&]() { \
+            load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr); \
+            if (seg > 0u) /* row L + 1 exists (never written: garbage, unused) */                  \
+                bnx = SegBnd{bsrc[4u * j + 4u], bsrc[4u * j + 5u], bsrc[4u * j + 6u], bsrc[4u * j + 7u]}; \
+        });                                                                                       \
+        bnd = bnx;                                                                                \
+        ++j;                                                                                      \
+    }
+            if (last)
+            {
+                while (j + 4 <= L)
+                {
+                    DCP_SROW(1, true) DCP_SROW(2, true) DCP_SROW(3, true) DCP_SROW(4, true) DCP_SROW(0, true)
+                }
+                if (j <= L) DCP_SROW(1, true)
+                if (j <= L) DCP_SROW(2, true)
+                if (j <= L) DCP_SROW(3, true)
+                if (j <= L) DCP_SROW(4, true)
+            }
+            else
+            {
+                while (j + 4 <= L)
+                {
+                    DCP_SROW(1, false) DCP_SROW(2, false) DCP_SROW(3, false) DCP_SROW(4, false) DCP_SROW(0, false)
+                }
+                if (j <= L) DCP_SROW(1, false)
+                if (j <= L) DCP_SROW(2, false)
+                if (j <= L) DCP_SROW(3, false)
+                if (j <= L) DCP_SROW(4, false)
+            }
+#undef DCP_SROW
+            dirty = dirty || __any(seg_dirty);
+        }
+        if (dirty)
+        {
+            if (lane == 0u)
+            {
+                unsigned const h = atomicAdd(a.seg_redo_n, 1u);
+                if (h < a.seg_redo_cap) a.seg_redo[h] = dcp_pair{q, slot};
+            }
+            continue;
+        }
+        float const C = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 2));
+        float const nul = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 3));
+        float const alt = fmaxf(o.E + xt[DCP_X_ET], C + xt[DCP_X_CT]);
+        if (lane == 0u)
+        {
+            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
+            if (a.out_null) a.out_null[oi] = nul;
+            if (a.out_alt) a.out_alt[oi] = alt;
+            float const lrt = -2 * (nul - alt);
+            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+            {
+                unsigned const h = atomicAdd(a.nhits, 1u);
+                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+            }
+        }
     }
 }
 
@@ -1352,6 +1598,18 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
 #undef DCP_CASE_S
     if (stg != 0) return -1;
     return dcp_launch_rowsweep(R, W, a, nblocks, stream);
+}
+
+// Segmented sweep of a multi-wavefront class whose capacity is a multiple of 64 x R (R = 6: the R = 3 classes);
+// != 0 if there is no such kernel.  seg_scratch must hold nblocks x 4 columns of a->seg_stride float4.
+extern "C" int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream)
+{
+    if (R == 3 && W > 1)
+    {
+        hipLaunchKernelGGL((viterbi_segsweep_kernel<6>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
+        return 0;
+    }
+    return -1;
 }
 
 // unstaged kernels: pair mode (a->pairs), the classes of several wavefronts per pair, and grid mode without staging

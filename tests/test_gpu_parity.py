@@ -645,6 +645,48 @@ def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves,
         hooks_scanner.test_set_rowsweep_variant(-1, 0)
 
 
+@pytest.mark.parametrize("multi", [True, False])
+def test_segmented_sweep_bit_exact(dcp, oracle32, hooks_scanner, multi):
+    """Profiles of more than 512 nodes in grid mode: one wavefront per pair sweeps the profile's 384-node segments one
+    after the other with B(j) = N(j) + NB (viterbi_segsweep_kernel), and the pairs whose E -> B / J -> B feedback
+    beat that B -- planted hits here -- are finished by the exact multi-wavefront kernel behind it.  Forced on for
+    every batch size through the test-hooks build (the library uses it from 32 queries on), against the oracle's
+    float32 recursion on the product's tables, bit for bit; a flagged (positive MD / DD) profile goes to the exact
+    kernel whole.  Classes without a segmented kernel (769..1024, 1537..2048 nodes) run beside it."""
+    rng = np.random.default_rng(9090 + int(multi))
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    sizes = (513, 600, 767, 768, 900, 1100, 1536, 1700, 2500, 3072, 300)
+    params = [pfam_like_params(rng, M) for M in sizes]
+    null, match, trans = pfam_like_params(rng, 640)
+    trans = trans.copy()
+    trans[1:640, 2] = np.float32(0.7)
+    trans[1:640, 6] = np.float32(0.4)
+    params.append((null, match, trans))
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    oprofs = [oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01) for prm in params]
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    hooks_scanner.upload_db(profiles, expand_on_host=True)
+    try:
+        for nseq in (1, 5, 37):
+            seqs = rand_seqs(rng, nseq, 1, 260)
+            if nseq > 1:  # homologous queries: the multi-hit feedback path
+                seqs[0] = planted_query(rng, oprofs[1], sizes[1], flank=15)
+                seqs[-1] = planted_query(rng, oprofs[6], sizes[6], flank=9)
+            hooks_scanner.upload_seqs(seqs)
+            hooks_scanner.test_set_rowsweep_variant(20, 4 | (2 << 24))  # segmented sweep: always
+            hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+            gn, ga = hooks_scanner.scores()
+            on, oa = oracle_dp_on_product_tables(dcp, oracle32, hooks_scanner, profiles, seqs, multi, False, True)
+            assert same_bits(gn, on) and same_bits(ga, oa), (nseq, multi)
+            hooks_scanner.test_set_rowsweep_variant(20, 4 | (1 << 24))  # the same batch without it
+            hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+            en, ea = hooks_scanner.scores()
+            assert same_bits(gn, en) and same_bits(ga, ea)
+    finally:
+        hooks_scanner.test_set_rowsweep_variant(-1, 0)
+
+
 def test_qlane_at_block_scale(dcp, oracle32, scanner):
     """The throughput kernel with every lane in use: 700 queries (2 full 256-query blocks + a partial
     one, lengths 1..400 so the length sort matters) x 45 profiles of mixed sizes (more tasks than a
