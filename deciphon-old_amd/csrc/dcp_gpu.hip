@@ -381,7 +381,9 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         // size distribution (24 -> 20.6 GB for the 20 000-profile DB), fewer HBM and L2 lines per DP row.
         SizeClass const sc = kClasses[cls[p]];
         unsigned ldk = sc.cap();
-        if (sc.W == 1 && c->core_sizes[p] <= 63u * (unsigned)sc.R) ldk = (c->core_sizes[p] + (unsigned)sc.R + 3u) & ~3u; // (rows rounded up to 128 bytes instead: no difference, measured)
+        if (sc.W == 1 && c->core_sizes[p] <= 63u * (unsigned)sc.R) ldk = (c->core_sizes[p] + (unsigned)sc.R + 3u) & ~3u;
+        // several wavefronts per pair: the same, with room for the segmented sweep's 6-node lanes in the tail
+        if (sc.W > 1) ldk = std::min(ldk, (c->core_sizes[p] + 8u + 3u) & ~3u); // (rows rounded up to 128 bytes instead: no difference, measured)
         dcp_prof_meta &m = c->metas[i];
         m.emis_off = emis_floats;
         m.trans_off = (uint32_t)trans_floats;

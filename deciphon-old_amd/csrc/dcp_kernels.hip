@@ -690,15 +690,16 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R, W)) vo
     float const *__restrict__ em_base = a.emis_match + pm.emis_off;
     cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
     cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
-    // Row length of the profile's tables.  W > 1: the class capacity.  W == 1: core_size + R rounded up to 4, so
-    // that every row (emissions and transitions alike) ends in at least R columns of -inf: a lane past the
-    // last node reads THOSE -- the same few bytes for all such lanes -- instead of owning padding columns of
-    // its own, and a row is 15 % shorter on a Pfam-like size distribution (dcp_gpu_db_upload).
+    // Row length of the profile's tables: core_size + R (+ 8 for the classes of several wavefronts) rounded up to
+    // 4, at most the class capacity, so that every row (emissions and transitions alike) ends in columns of -inf:
+    // a lane past the last node reads THOSE -- the same few bytes for all such lanes -- instead of owning padding
+    // columns of its own, and a row is 15-20 % shorter on a Pfam-like size distribution (dcp_gpu_db_upload).
     unsigned const ldk = pm.ldk;
     // wave-uniform and opaque: a scalar compare and branch per row (as a plain bool the condition is
     // re-materialised through a v_cndmask / v_cmp pair in every row)
     unsigned const exact_e = __builtin_amdgcn_readfirstlane(pm.flags & DCP_PROF_EXACT_E);
-    unsigned const lane_off = W == 1 ? (lane * R < pm.core_size ? lane * R : ldk - R) : (wave * 64u + lane) * R;
+    unsigned const node0 = (W == 1 ? lane : wave * 64u + lane) * R; // this lane's first node
+    unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the row's -inf tail
     unsigned gen = 0;
     if constexpr (STAGED > 0)
     {
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void viterbi_segsweep_kernel(dcp_scan_args 
         unsigned const slot = __builtin_amdgcn_readfirstlane(a.first_prof + s_rel);
         unsigned const q = __builtin_amdgcn_readfirstlane(task - s_rel * a.nseqs);
         dcp_prof_meta const pm = a.profs[slot];
-        unsigned const ldk = pm.ldk; // the class capacity: a multiple of 64 x R
+        unsigned const ldk = pm.ldk; // core_size + 8 rounded up to 4, at most the class capacity (a multiple of 64 x R)
         unsigned const nseg = (pm.core_size + 64u * R - 1u) / (64u * R);
         bool dirty = (pm.flags & DCP_PROF_EXACT_E) != 0u;
         float const *__restrict__ em_prof = a.emis_match + pm.emis_off;
@@ -901,7 +902,8 @@ __global__ __launch_bounds__(256, 2) void viterbi_segsweep_kernel(dcp_scan_args 
         for (unsigned seg = 0; seg < nseg && !dirty; ++seg) // `dirty` is wave-uniform
         {
             bool const last = seg + 1u == nseg;
-            unsigned const lane_off = seg * 64u * R + lane * R;
+            unsigned const node0 = seg * 64u * R + lane * R;
+            unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the -inf tail
             float const *__restrict__ em_base = em_prof; // wave-uniform; the lane's columns through lane_boff
             Trans<R> t;
             {
