@@ -30,8 +30,9 @@ for var in variants or [None]:
             sc.scan(True, False, 10.0, keep_scores=False, sync=True, q_range=(0, nq), kernel=dcp.KERNEL_ROWSWEEP)
         out.append(f"{nq}: {sc.last_scan_ms:.1f} ms ({cellsM*nq*1000/(sc.last_scan_ms*1e-3)/1e9:.0f})")
         if os.environ.get("RS_CLASSES") and nq * 20000 >= (1 << 21):  # smaller scans fork the class launches
-            t0, per = 0.0, {}
-            for li in sc.launch_infos():
-                per[f"R{li['R']}W{li['W']}"] = round(li["ms"] - t0, 1); t0 = li["ms"]
+            per = {}
+            for li in sc.launch_infos():  # ms of each launch (a segmented class: its sweep + its redo launch)
+                key = f"R{li['R']}W{li['W']}"
+                per[key] = round(per.get(key, 0.0) + li["ms"], 1)
             out.append(str(per))
     print(f"rowsweep {var if var else 'auto'}  " + "   ".join(out), flush=True)

@@ -1,3 +1,5 @@
+"""Per-launch times of one row-sweep scan of the C3 step (1 000 queries): a segmented class shows as two launches
+   (the sweep, then the exact kernel on its redo list).  python3 profiles/seg_split_probe.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, bench
