@@ -618,7 +618,10 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 #ifndef DCP_RS_R4_WAVES
 #define DCP_RS_R4_WAVES 4 // wavefronts per SIMD of the R = 4 one-wavefront class: 4 = 128 VGPRs with 23 spilled (35 GB of scratch traffic per C3 launch), 3 = 168 and none -- measured: 538 vs 573 ms, occupancy wins
 #endif
-constexpr int rs_min_waves(int R, int W = 1) { return R <= 3 ? 4 : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4) : 2; }
+#ifndef DCP_RS_R2_WAVES
+#define DCP_RS_R2_WAVES 6 // wavefronts per SIMD of the R = 2 class: 6 = 80 VGPRs with 5 spilled, against 5 at 85 without --
+#endif                     // R2W1 launch 712 -> 683 ms (7 = 72 VGPRs, 27 spilled: another 1.4 %, not taken)
+constexpr int rs_min_waves(int R, int W = 1) { return R == 2 ? DCP_RS_R2_WAVES : R <= 3 ? 4 : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4) : 2; }
 // STG (W == 1 only): leading rows of the profile's emission table a block keeps in LDS -- 20 (the words of one
 // and two bases) or 84 (three bases as well).  A staged block is 1..16 wavefronts (blockDim.x / 64) scoring
 // consecutive queries against ONE profile, whose rows they first copy together; it is sized by the launcher so
@@ -626,7 +629,7 @@ constexpr int rs_min_waves(int R, int W = 1) { return R <= 3 ? 4 : R == 4 ? (W =
 // STG == 0: every wavefront has its own task -- a (query, profile) pair of a device-side list (the pairs the
 // query-lane kernel could not finish, dcp_qlane.hip: a persistent grid strides over the list) or, without a
 // list, chunk `task % nchunks` of profile `task / nchunks`.
-constexpr int rs_block_threads(int R, int W, int STG) { return W > 1 ? 64 * W : STG > 0 ? 256 * rs_min_waves(R) : 256; }
+constexpr int rs_block_threads(int R, int W, int STG) { return W > 1 ? 64 * W : STG > 0 ? (rs_min_waves(R) >= 4 ? 1024 : 256 * rs_min_waves(R)) : 256; }
 // PF (staged variants): the rows that still come from global memory are fetched TWO DP rows ahead -- the variants of
 // the small batches, which wait for HBM latency (one query: a wavefront's row takes as long as its loads).
 template <int R, int W, int STG, bool PF>
@@ -1560,8 +1563,8 @@ extern "C" unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg)
 {
     if (W != 1) return stg == 0 ? 1u : 0u;
     if (stg == 0) return 4u;
-    if (stg == 20) return R >= 1 && R <= 8 ? 4u * (unsigned)rs_min_waves(R) : 0u;
-    if (stg == 84) return R >= 1 && R <= 7 ? 4u * (unsigned)rs_min_waves(R) : 0u; // R = 8: 172 KB
+    if (stg == 20) return R >= 1 && R <= 8 ? (unsigned)rs_block_threads(R, 1, 20) / 64u : 0u;
+    if (stg == 84) return R >= 1 && R <= 7 ? (unsigned)rs_block_threads(R, 1, 84) / 64u : 0u; // R = 8: 172 KB
     return 0u;
 }
 extern "C" unsigned dcp_rowsweep_stage_bytes(int R, int stg) { return (unsigned)stg * 64u * (unsigned)R * 4u; }
