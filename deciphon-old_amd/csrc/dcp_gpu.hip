@@ -1216,7 +1216,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         bool const want = c->seg_mode == 1 || (c->seg_mode < 0 && nq >= 32u);
         bool const have = sc.W > 1 && sc.R == 3 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
         if (!have) continue;
-        uint64_t nb = std::min<uint64_t>((pairs + 3u) / 4u, 2ull * c->num_cus); // 2 wavefronts per SIMD
+        uint64_t nb = std::min<uint64_t>((pairs + 3u) / 4u, (uint64_t)dcp_segsweep_blocks_per_cu() * c->num_cus);
         nb = (nb + 7u) / 8u * 8u;
         uint64_t const scr = nb * 4u * seg_stride * 4u; // floats
         if ((seg_scr_tot + scr) * sizeof(float) > ((uint64_t)8 << 30)) continue; // very long sequences: the exact kernel

@@ -176,6 +176,7 @@ int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
 unsigned dcp_rowsweep_tasks_per_block(int W);
 // one wavefront per pair over the segments of a profile of a multi-wavefront class; != 0: no such kernel
 int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
+unsigned dcp_segsweep_blocks_per_cu(void); // resident 256-thread blocks per CU of that kernel
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large
 int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,

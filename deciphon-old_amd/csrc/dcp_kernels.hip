@@ -621,19 +621,33 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 #ifndef DCP_RS_R2_WAVES
 #define DCP_RS_R2_WAVES 6 // wavefronts per SIMD of the R = 2 class: 6 = 80 VGPRs with 5 spilled, against 5 at 85 without --
 #endif                     // R2W1 launch 712 -> 683 ms (7 = 72 VGPRs, 27 spilled: another 1.4 %, not taken)
-constexpr int rs_min_waves(int R, int W = 1) { return R == 2 ? DCP_RS_R2_WAVES : R <= 3 ? 4 : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4) : 2; }
-// STG (W == 1 only): leading rows of the profile's emission table a block keeps in LDS -- 20 (the words of one
-// and two bases) or 84 (three bases as well).  A staged block is 1..16 wavefronts (blockDim.x / 64) scoring
-// consecutive queries against ONE profile, whose rows they first copy together; it is sized by the launcher so
-// that the CU's wavefront slots stay filled although an 84-row image takes 21.5 KB x R of its LDS.
-// STG == 0: every wavefront has its own task -- a (query, profile) pair of a device-side list (the pairs the
-// query-lane kernel could not finish, dcp_qlane.hip: a persistent grid strides over the list) or, without a
-// list, chunk `task % nchunks` of profile `task / nchunks`.
-constexpr int rs_block_threads(int R, int W, int STG) { return W > 1 ? 64 * W : STG > 0 ? (rs_min_waves(R) >= 4 ? 1024 : 256 * rs_min_waves(R)) : 256; }
+// R = 5 and 6: three wavefronts per SIMD (168 VGPRs, 53 / 173 spilled) instead of two: R5W1 launch 448 -> 384 ms,
+// R6W1 269 -> 228; R = 7 at three (425 spilled: 171 -> 484 ms) and R = 5 at four (316 spilled: 374 -> 673) lose
+#ifndef DCP_RS_R5_WAVES
+#define DCP_RS_R5_WAVES 3
+#endif
+#ifndef DCP_RS_R6_WAVES
+#define DCP_RS_R6_WAVES 3
+#endif
+#ifndef DCP_RS_R7_WAVES
+#define DCP_RS_R7_WAVES 2
+#endif
+// `big`: the variant of the large batches (20 rows staged, one row of prefetch).  Only there do R = 5, 6 run three
+// wavefronts per SIMD: the small batches wait for HBM, and the spilled registers' scratch traffic costs them more
+// than the third wavefront hides (1 query 11.7 -> 13.9 ms, 16 queries 80 -> 84 with it everywhere).
+constexpr int rs_min_waves(int R, int W = 1, bool big = false)
+{
+    return R == 2 ? DCP_RS_R2_WAVES : R <= 3 ? 4 : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4)
+           : R == 5 ? (big ? DCP_RS_R5_WAVES : 2) : R == 6 ? (big ? DCP_RS_R6_WAVES : 2) : R == 7 ? DCP_RS_R7_WAVES : 2;
+}
+constexpr int rs_block_threads(int R, int W, int STG, bool PF = false)
+{
+    return W > 1 ? 64 * W : STG > 0 ? (rs_min_waves(R, W, STG == 20 && !PF) >= 4 ? 1024 : 256 * rs_min_waves(R, W, STG == 20 && !PF)) : 256;
+}
 // PF (staged variants): the rows that still come from global memory are fetched TWO DP rows ahead -- the variants of
 // the small batches, which wait for HBM latency (one query: a wavefront's row takes as long as its loads).
 template <int R, int W, int STG, bool PF>
-__global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R, W)) void viterbi_rowsweep_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W, STG == 20 && !PF)) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
     static_assert(!PF || STG > 0, "only staged variants prefetch two rows ahead");
     static_assert(W == 1 || STG == 0, "only one-wavefront pairs stage rows");
@@ -866,8 +880,11 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG), rs_min_waves(R, W)) vo
 // of a profile flagged DCP_PROF_EXACT_E, are appended to `seg_redo` for the exact kernel (pair mode), which runs
 // right behind on the same stream.  Each wavefront owns a scratch column of 2 x (lmax + 2) rows of 16 bytes.
 // ============================================================================
+#ifndef DCP_SEG_WAVES
+#define DCP_SEG_WAVES 2
+#endif
 template <int R>
-__global__ __launch_bounds__(256, 2) void viterbi_segsweep_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segsweep_kernel(dcp_scan_args a)
 {
     unsigned const lane = threadIdx.x & 63u;
     unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1563,7 +1580,8 @@ extern "C" unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg)
 {
     if (W != 1) return stg == 0 ? 1u : 0u;
     if (stg == 0) return 4u;
-    if (stg == 20) return R >= 1 && R <= 8 ? (unsigned)rs_block_threads(R, 1, 20) / 64u : 0u;
+    // (the narrower of the variant with and without the two-row prefetch: one answer per class and image)
+    if (stg == 20) return R >= 1 && R <= 8 ? (unsigned)std::min(rs_block_threads(R, 1, 20, false), rs_block_threads(R, 1, 20, true)) / 64u : 0u;
     if (stg == 84) return R >= 1 && R <= 7 ? (unsigned)rs_block_threads(R, 1, 84) / 64u : 0u; // R = 8: 172 KB
     return 0u;
 }
@@ -1604,6 +1622,8 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
     if (stg != 0) return -1;
     return dcp_launch_rowsweep(R, W, a, nblocks, stream);
 }
+
+extern "C" unsigned dcp_segsweep_blocks_per_cu(void) { return DCP_SEG_WAVES; } // four-wavefront blocks: its waves per SIMD
 
 // Segmented sweep of a multi-wavefront class whose capacity is a multiple of 64 x R (R = 6: the R = 3 classes);
 // != 0 if there is no such kernel.  seg_scratch must hold nblocks x 4 columns of a->seg_stride float4.
