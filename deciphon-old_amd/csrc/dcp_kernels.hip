@@ -632,12 +632,19 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 #ifndef DCP_RS_R7_WAVES
 #define DCP_RS_R7_WAVES 2
 #endif
+#ifndef DCP_RS_R2_BIG_WAVES
+#define DCP_RS_R2_BIG_WAVES 7 // R2W1 launch 694 -> 684 ms (72 VGPRs, 27 spilled)
+#endif
+#ifndef DCP_RS_R3_BIG_WAVES
+#define DCP_RS_R3_BIG_WAVES 5 // R3W1 launch 754 -> 739 ms (96 VGPRs)
+#endif
 // `big`: the variant of the large batches (20 rows staged, one row of prefetch).  Only there do R = 5, 6 run three
 // wavefronts per SIMD: the small batches wait for HBM, and the spilled registers' scratch traffic costs them more
 // than the third wavefront hides (1 query 11.7 -> 13.9 ms, 16 queries 80 -> 84 with it everywhere).
 constexpr int rs_min_waves(int R, int W = 1, bool big = false)
 {
-    return R == 2 ? DCP_RS_R2_WAVES : R <= 3 ? 4 : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4)
+    return R == 2 ? (big ? DCP_RS_R2_BIG_WAVES : DCP_RS_R2_WAVES) : R == 3 && W == 1 && big ? DCP_RS_R3_BIG_WAVES : R <= 3 ? 4
+           : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4)
            : R == 5 ? (big ? DCP_RS_R5_WAVES : 2) : R == 6 ? (big ? DCP_RS_R6_WAVES : 2) : R == 7 ? DCP_RS_R7_WAVES : 2;
 }
 constexpr int rs_block_threads(int R, int W, int STG, bool PF = false)
