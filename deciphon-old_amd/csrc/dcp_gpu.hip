@@ -989,11 +989,13 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 sum_block_lmax += len[std::min(nq, (b + 1u) * NTq) - 1u];
             unsigned const lmax = len.back();
             double t_rs = (double)c->sum_core * (DCP_NCODES * 4.0) / 3e12 + a.qchunk * lmax * 1.2e-6; // 1.2 us per row
+            // (the class rates are those of a 1 000-query step; between 64 and 256 queries the row sweep runs 5 %
+            // below them -- 128 queries 450 ms, 160: 558 -- profiles/r03/switch_probe.txt)
             for (int k = 0; k < kNumClasses; ++k)
-                t_rs += (double)c->class_core[k] * sum_len / kClassRate[k];
+                t_rs += 1.05 * (double)c->class_core[k] * sum_len / kClassRate[k];
             unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
             // (round 3, 20k-profile DB: 96 and 128 queries 477 / 480 ms, 256 queries 659 ms in the single-stage kernel)
-            static double const kTrow[4] = {0.52, 0.54, 0.64, 0.73};
+            static double const kTrow[4] = {0.52, 0.54, 0.62, 0.73}; // 144..191 queries: 544-555 ms
             double const trow = (w3 ? 0.56 : kTrow[waves - 1u]) * 1e-6; // w3: + one add per gather
             double const resident = (double)std::min<uint64_t>((uint64_t)c->nprof * nqb, (uint64_t)ql_blocks_per_cu * c->num_cus);
             double const t_ql = std::max((double)c->max_tiles * lmax * 0.52e-6,
@@ -1004,7 +1006,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             // 256 queries 641 vs 678 ms, 1024 queries 2508 vs 2657 ms (0.94); below that its idle
             // wavefronts still sit through every barrier (128 queries 583 vs 514 ms).  With fewer tasks
             // than blocks fit on the chip it takes 0.66 of the single-stage time (profiles/smalldb_probe.py).
-            bool const stage2 = nq >= 192u;
+            bool const stage2 = nq > 192u; // 192 queries (three full wavefronts per block): 555 ms single-stage, 569 two-stage; 224: 654 / 628
             double const fill = std::min(1.0, (double)c->nprof * nqb / (4.0 * c->num_cus));
             double const t_q = stage2 ? t_ql * (0.66 + 0.28 * fill) : t_ql;
             kernel = t_q < t_rs ? (stage2 ? 3 : 2) : 1;

@@ -841,7 +841,7 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
             if name == "qlane":
                 redo = sc.last_scan_redo_pairs
         assert 0 < redo < 0.05 * 2e7
-        # kernel = 0 on this DB: the row sweep up to about 115 queries (64 queries: 283 ms against 330 ms),
+        # kernel = 0 on this DB: the row sweep up to about 150 queries (128 queries: 450 ms against 479 ms),
         # the single-stage query-lane kernel from there, the two-stage one once the blocks are mostly full
         sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 16))
         assert sc.launch_infos()[0]["W"] >= 1 and sc.last_scan_kernel == dcp.KERNEL_ROWSWEEP
