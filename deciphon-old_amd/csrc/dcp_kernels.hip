@@ -632,6 +632,9 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 #ifndef DCP_RS_R7_WAVES
 #define DCP_RS_R7_WAVES 2
 #endif
+#ifndef DCP_RS_PAIR_BIG
+#define DCP_RS_PAIR_BIG 0 // 1: the pair-mode kernels (redo lists) at the large-batch variants' occupancy
+#endif
 #ifndef DCP_RS_R2_BIG_WAVES
 #define DCP_RS_R2_BIG_WAVES 7 // R2W1 launch 694 -> 684 ms (72 VGPRs, 27 spilled)
 #endif
@@ -654,7 +657,7 @@ constexpr int rs_block_threads(int R, int W, int STG, bool PF = false)
 // PF (staged variants): the rows that still come from global memory are fetched TWO DP rows ahead -- the variants of
 // the small batches, which wait for HBM latency (one query: a wavefront's row takes as long as its loads).
 template <int R, int W, int STG, bool PF>
-__global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W, STG == 20 && !PF)) void viterbi_rowsweep_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W, (STG == 20 && !PF) || (STG == 0 && W == 1 && DCP_RS_PAIR_BIG))) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
     static_assert(!PF || STG > 0, "only staged variants prefetch two rows ahead");
     static_assert(W == 1 || STG == 0, "only one-wavefront pairs stage rows");
