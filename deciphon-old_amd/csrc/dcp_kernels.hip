@@ -632,6 +632,9 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 #ifndef DCP_RS_R7_WAVES
 #define DCP_RS_R7_WAVES 2
 #endif
+#ifndef DCP_RS_R4_BIG_WAVES
+#define DCP_RS_R4_BIG_WAVES DCP_RS_R4_WAVES
+#endif
 #ifndef DCP_RS_PAIR_BIG
 #define DCP_RS_PAIR_BIG 0 // 1: the pair-mode kernels (redo lists) at the large-batch variants' occupancy
 #endif
@@ -647,7 +650,7 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
 constexpr int rs_min_waves(int R, int W = 1, bool big = false)
 {
     return R == 2 ? (big ? DCP_RS_R2_BIG_WAVES : DCP_RS_R2_WAVES) : R == 3 && W == 1 && big ? DCP_RS_R3_BIG_WAVES : R <= 3 ? 4
-           : R == 4 ? (W == 1 ? DCP_RS_R4_WAVES : 4)
+           : R == 4 ? (W == 1 ? (big ? DCP_RS_R4_BIG_WAVES : DCP_RS_R4_WAVES) : 4)
            : R == 5 ? (big ? DCP_RS_R5_WAVES : 2) : R == 6 ? (big ? DCP_RS_R6_WAVES : 2) : R == 7 ? DCP_RS_R7_WAVES : 2;
 }
 constexpr int rs_block_threads(int R, int W, int STG, bool PF = false)
