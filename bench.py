@@ -313,6 +313,202 @@ def stub_rank(args, rank, world):
     dist.destroy_process_group()
 
 
+class TimedLeg:
+    """What the timed region measured, captured INSIDE it (the later legs scan on the same context)."""
+
+    def __init__(self):
+        self.per_class = {}      # (R, W) -> ms / algorithmic bytes / cells / launches, HIP events on the launch stream
+        self.kernel_ms = 0.0
+        self.redo_pairs = 0
+        self.kernels = {}        # dcp_gpu_last_scan_kernel of every timed step -> steps
+        self.elapsed = 0.0
+
+    @property
+    def kernel(self):
+        """The kernel the timed steps ran with (the one most steps ran with, should they differ)."""
+        return max(self.kernels, key=self.kernels.get) if self.kernels else None
+
+
+def timed_leg(sc, step, first, last, fence):
+    """EXACTLY last - first steps between two fences; launch records and the kernel id are read per step."""
+    cap = TimedLeg()
+    t0 = time.perf_counter()
+    for i in range(first, last):
+        step(i)
+        for li in sc.launch_infos():  # HIP events on the launch stream, read after the sync
+            k = (li["R"], li["W"])
+            acc = cap.per_class.setdefault(k, dict(ms=0.0, bytes=0, cells=0, launches=0))
+            acc["ms"] += li["ms"]
+            acc["bytes"] += li["algorithmic_bytes"]
+            acc["cells"] += li["cells"]
+            acc["launches"] += 1
+        cap.kernel_ms += sc.last_scan_ms
+        cap.redo_pairs += sc.last_scan_redo_pairs
+        kid = sc.last_scan_kernel
+        cap.kernels[kid] = cap.kernels.get(kid, 0) + 1
+    fence()
+    cap.elapsed = time.perf_counter() - t0
+    return cap
+
+
+def small_batches_leg(sc, dcp, src, qlen, sum_m, fetch_hits):
+    """N = 1, after the timed regions: what the reference's own loop sees -- it scans ONE sequence at a time
+    (src/server/scan.c:227-258) -- and batches of 8 and 64: upload + scan of the whole DB + hits on the host per
+    batch, automatic kernel choice (the row sweep at these sizes), median of three."""
+    small = {}
+    for nq_small in (1, 8, 64):
+        if nq_small > len(src):
+            continue
+        batch = src[:nq_small]
+        ts = []
+        for _rep in range(4):
+            t0 = time.perf_counter()
+            if qlen:
+                sc.upload_seqs_flat(np.ascontiguousarray(batch).reshape(-1),
+                                    (np.arange(nq_small + 1, dtype=np.uint64) * qlen).astype(np.uint32))
+            else:
+                sc.upload_seqs(batch)
+            sc.scan(True, False, 10.0, keep_scores=False, sync=True, kernel=dcp.KERNEL_AUTO)
+            fetch_hits()
+            ts.append(time.perf_counter() - t0)
+        t_med = sorted(ts[1:])[1]
+        cells_small = sum_m * float(sum(len(x) for x in batch))
+        small[str(nq_small)] = {"ms": round(t_med * 1e3, 2), "kernel_ms": round(sc.last_scan_ms, 2),
+                                "seqs_per_sec": round(nq_small / t_med, 1),
+                                "gcells_per_s": round(cells_small / t_med / 1e9, 1)}
+    small["what"] = ("per batch: host sequences -> upload -> scan of the whole resident DB (automatic kernel choice: "
+                     "the row sweep at these sizes) -> hit records on the host; median of 3 after one untimed pass")
+    return small
+
+
+def roofline_block(timed, dcp, workload, steps, sizes, b, e, qstep, world, qlen):
+    """The `roofline` object of the JSON line, from the TIMED leg's capture only (never from the context's
+    current state: tests/test_bench_roofline.py runs a kernel-switching later leg in between)."""
+    per_class, kernel_ms, redo_pairs = timed.per_class, timed.kernel_ms, timed.redo_pairs
+    dom_key = max(per_class, key=lambda k: per_class[k]["ms"])
+    dom = per_class[dom_key]
+    dom_ms = dom["ms"] / dom["launches"]
+    dom_cells = dom["cells"] / dom["launches"]
+    dom_algo_bytes = dom["bytes"] / dom["launches"]
+    is_qlane = not dom_key[1]
+    kname = (f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>" if dom_key[1] else
+             f"viterbi_qlane{'2' if timed.kernel == dcp.KERNEL_QLANE2 else ''}_kernel<KT={dom_key[0]}>")
+    # What binds the dominant kernel (DESIGN.md §4): VALU ISSUE.  28 max/add lane-ops per cell
+    # (SURVEY.md 8d: 11 for M_k, 10 for I_k, 3 for D_k, 4 for E/B) against the chip's f32 VALU rate:
+    # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s (= 157.3 TFLOPS / 2: max and
+    # add, no FMA to fuse).  SURVEY 8d's HBM model (20 B/cell) is reported as `algorithmic_hbm`:
+    # those bytes are LDS gathers in the query-lane kernel and L2 hits in the row sweep.
+    VALU_PEAK = 78.6e12
+    OPS_PER_CELL = 28
+    lane_ops = dom_cells * OPS_PER_CELL / (dom_ms * 1e-3)
+    # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the
+    # figure is REPLAYED from the committed rocprofv3 --pmc passes of this same command (see
+    # traffic_source); null when no matching profile is committed.
+    traffic, traffic_source = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm.json")))
+        if pmc.get("workload") == workload and pmc.get("queries_per_step") == qstep and world == 1:
+            for pmc_name, pmc_entry in pmc["kernels"].items():
+                if kname.split("<")[0] in pmc_name and "hbm_bytes_per_launch" in pmc_entry:
+                    traffic = pmc_entry["hbm_bytes_per_launch"]
+                    traffic_source = ("replayed (not measured in this run) from profiles/latest_pmc_hbm.json: "
+                                      + pmc.get("note", ""))
+    except (OSError, ValueError, KeyError):
+        pass
+    # What the VALU can do with THIS instruction mix: the row's arithmetic alone, measured in a registers-only
+    # microbenchmark (profiles/microbench/row_valu.hip; replayed like the PMC traffic).  28 ops per cell at
+    # the 2-cycle rate is not attainable for a max-plus recursion on gfx950: v_max_f32 / v_max3_f32 --
+    # a third of the ops -- and adds with an SGPR operand issue at half that rate (profiles/r03/valu_issue.txt).
+    valu_ceiling = None
+    try:
+        vc = json.load(open(os.path.join(ROOT, "profiles", "latest_valu_ceiling.json")))
+        cyc = float(vc["cycles_per_wavefront_row"])
+        at_spec = 256 * 4 * 64 * vc["nodes_per_lane"] / cyc * 2.4e9
+        valu_ceiling = {"cycles_per_wavefront_row_arithmetic_only": cyc,
+                        "gcells_per_s_at_2.4GHz": round(at_spec / 1e9, 1),
+                        "frac_of_ceiling": (round(dom_cells / (dom_ms * 1e-3) / at_spec, 4) if is_qlane else None),
+                        "source": "replayed from profiles/latest_valu_ceiling.json: " + vc["source"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    # analytic HBM traffic of the design, to hold against the measured figure:
+    #   query lane: 12 B written + 12 B read per (row, lane, tile boundary) -- the Xm/Xd/Em planes --
+    #               plus every tile image once per (profile, 256-query block)
+    #   compulsory: SURVEY 8d note 2 -- 548*M + L + 8 bytes per pair (compact profile streamed once)
+    ntiles = (sizes[b:e].astype(np.int64) + 7) // 8
+    lanes = ((qstep // world + 63) // 64) * 64 if qlen else None
+    two_stage = timed.kernel == dcp.KERNEL_QLANE2
+    hbm_boundaries = ((ntiles - 1) // 2) if two_stage else (ntiles - 1)  # odd -> even only / every boundary
+    scratch_bytes = (int(24 * int(hbm_boundaries.sum()) * lanes * qlen) if (is_qlane and qlen) else None)
+    tile_bytes = (int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep // world + 255) // 256) if is_qlane else None)
+    npairs_launch = (e - b) * (qstep // world)
+    compulsory = int(548 * int(sizes[b:e].sum()) * (qstep // world) + (qlen + 8) * npairs_launch) if qlen else None
+    roof = {
+        "bound": "valu-issue",
+        "kernel": kname,
+        # dcp_gpu_last_scan_kernel of every timed step (1 row sweep, 2 single-stage, 3 two-stage query lane)
+        "timed_step_kernels": {str(k): v for k, v in sorted(timed.kernels.items())},
+        "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK / 1e12, 1), "unit": "Tlane-op/s",
+        "frac": round(lane_ops / VALU_PEAK, 4),
+        "ops_per_cell": OPS_PER_CELL,
+        "valu_only_ceiling": valu_ceiling,
+        "peak_note": ("256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (spec clock); measured clock under this load: two-stage "
+                      "query-lane kernel 2.23 GHz, single-stage 1.81 GHz, row sweep 2.3-2.4 GHz (profiles/r02/*pmc*)"),
+        "avg_launch_ms": round(dom_ms, 3),
+        "cells_per_launch": int(dom_cells),
+        "gcells_per_s": round(dom_cells / (dom_ms * 1e-3) / 1e9, 1),
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "hbm": {
+            "peak_gbs": 8000.0,
+            "measured_gbs": (round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
+            "measured_frac": (round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic else None),
+            # north_star's "achieved HBM GB/s against the chip's peak", spelled out: counter bytes of THIS kernel
+            # (replayed, see traffic_source) / this run's average launch time / 8 TB/s
+            "achieved_gbs": (round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
+            "achieved_frac": (round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic else None),
+            "analytic_scratch_plane_bytes_per_launch": scratch_bytes,
+            "analytic_tile_image_bytes_per_launch": tile_bytes,
+            "compulsory_bytes_per_launch": compulsory,
+        },
+        # the row sweep reads SURVEY 8d's 20 B/cell of match emissions on chip: since round 3 the rows of the
+        # 1- and 2-base words (8 of the 20 B) from the block's LDS image, the other 12 B/cell from the XCD's L2
+        # (the profile's table is L2-resident while its queries run): against the L2 peak
+        # (MI355X_MICROARCH.md: 34.5 TB/s; its measured rate for gathering L2-resident rows is 16.8-18.8 TB/s)
+        "l2_gather": (None if is_qlane else {
+            "bytes_per_launch": int(dom_algo_bytes * 12 / 20),
+            "bytes_per_cell": 12,
+            "gbs": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 1e9, 1),
+            "peak_gbs": 34500.0,
+            "frac": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 34.5e12, 3),
+            "lds_bytes_per_cell": 8,
+        }),
+        # SURVEY.md 8d's per-pair byte model 20*M*L + 32*(M+1) + L + 8: NOT a bound for this design
+        "algorithmic_hbm": {
+            "bytes_per_launch": int(dom_algo_bytes),
+            "gbs": round(dom_algo_bytes / (dom_ms * 1e-3) / 1e9, 1),
+            "ratio_to_hbm_peak": round(dom_algo_bytes / (dom_ms * 1e-3) / 8e12, 3),
+            "note": ("served from LDS: the 20 B/cell of match emissions are ds_read_b128 gathers from the "
+                     "LDS-resident tile image, never HBM reads -- a ratio above 1 is on-chip reuse, not a bound"
+                     if is_qlane else
+                     "served from L2/Infinity Cache: many queries re-read one profile's table rows"),
+        },
+        # where the query-lane kernel reads those bytes from: LDS, 256 B/clk/CU x 256 CUs x 2.4 GHz
+        # = 157 TB/s conflict-free (random 16-byte gathers serialise ~2.1x)
+        "lds": ({"bytes_per_cell": 20, "peak": 157286.0, "unit": "GB/s",
+                 "frac": round(dom_cells / (dom_ms * 1e-3) * 20 / 157.286e12, 4)} if is_qlane else None),
+        "kernel_ms_per_step": round(kernel_ms / steps, 3),
+        "per_class_ms_per_step": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"): round(v["ms"] / steps, 3)
+                                  for k, v in sorted(per_class.items())},
+        "per_class_gcells_per_s": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"):
+                                   round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1)
+                                   for k, v in sorted(per_class.items()) if v["cells"]},
+        # query-lane scans: pairs with multi-hit feedback are re-scored by the row-sweep
+        # launches (R*W* above) right after the query-lane kernel
+        "redo_pairs_per_step": round(redo_pairs / steps, 1),
+    }
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -509,23 +705,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    per_class = {}
-    kernel_ms = 0.0
-    redo_pairs = 0
-    t0 = time.perf_counter()
-    for i in range(args.warmup, nsteps):
-        step(i)
-        for li in sc.launch_infos():  # HIP events on the launch stream, read after the sync
-            k = (li["R"], li["W"])
-            acc = per_class.setdefault(k, dict(ms=0.0, bytes=0, cells=0, launches=0))
-            acc["ms"] += li["ms"]
-            acc["bytes"] += li["algorithmic_bytes"]
-            acc["cells"] += li["cells"]
-            acc["launches"] += 1
-        kernel_ms += sc.last_scan_ms
-        redo_pairs += sc.last_scan_redo_pairs
-    fence()
-    elapsed = time.perf_counter() - t0
+    # everything the roofline block says about "the dominant kernel" is captured HERE, inside the timed leg: the
+    # later legs (e2e, small batches, parity sample) scan on the same context and move sc.last_scan_kernel
+    timed = timed_leg(sc, step, args.warmup, nsteps, fence)
+    per_class, kernel_ms, redo_pairs, elapsed = timed.per_class, timed.kernel_ms, timed.redo_pairs, timed.elapsed
 
     cells_rank = float(sum(v["cells"] for v in per_class.values()))
 
@@ -576,31 +759,8 @@ def main():
     # batch, automatic kernel choice (the row sweep at these sizes), median of three; outside every timed region
     small = None
     if world == 1 and not force_dist and not args.dense and not args.stub_scan and args.kernel == "auto":
-        small = {}
-        src = small_src
-        for nq_small in (1, 8, 64):
-            if nq_small > len(src):
-                continue
-            batch = src[:nq_small]
-            ts = []
-            for _rep in range(4):
-                t0 = time.perf_counter()
-                if qlen:
-                    sc.upload_seqs_flat(np.ascontiguousarray(batch).reshape(-1),
-                                        (np.arange(nq_small + 1, dtype=np.uint64) * qlen).astype(np.uint32))
-                else:
-                    sc.upload_seqs(batch)
-                sc.scan(True, False, 10.0, keep_scores=False, sync=True, kernel=dcp.KERNEL_AUTO)
-                nh = min(cap, int(hit_count.item()))
-                _ = hit_words[:nh].cpu().numpy()
-                ts.append(time.perf_counter() - t0)
-            t_med = sorted(ts[1:])[1]
-            cells_small = float(sizes[b:e].sum()) * float(sum(len(x) for x in batch))
-            small[str(nq_small)] = {"ms": round(t_med * 1e3, 2), "kernel_ms": round(sc.last_scan_ms, 2),
-                                    "seqs_per_sec": round(nq_small / t_med, 1),
-                                    "gcells_per_s": round(cells_small / t_med / 1e9, 1)}
-        small["what"] = ("per batch: host sequences -> upload -> scan of the whole resident DB (automatic kernel choice: "
-                         "the row sweep at these sizes) -> hit records on the host; median of 3 after one untimed pass")
+        small = small_batches_leg(sc, dcp, small_src, qlen, float(sizes[b:e].sum()),
+                                  lambda: hit_words[:min(cap, int(hit_count.item()))].cpu().numpy())
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -611,121 +771,7 @@ def main():
         cells_total = cells_rank
 
     if rank == 0:
-        dom_key = max(per_class, key=lambda k: per_class[k]["ms"])
-        dom = per_class[dom_key]
-        dom_ms = dom["ms"] / dom["launches"]
-        dom_cells = dom["cells"] / dom["launches"]
-        dom_algo_bytes = dom["bytes"] / dom["launches"]
-        is_qlane = not dom_key[1]
-        kname = (f"viterbi_rowsweep_kernel<R={dom_key[0]},W={dom_key[1]}>" if dom_key[1] else
-                 f"viterbi_qlane{'2' if sc.last_scan_kernel == dcp.KERNEL_QLANE2 else ''}_kernel<KT={dom_key[0]}>")
-        # What binds the dominant kernel: VALU ISSUE.  28 max/add lane-ops per cell
-        # (11 for M_k, 10 for I_k, 3 for D_k, 4 for E/B) against the chip's f32 VALU rate:
-        # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s (= 157.3 TFLOPS / 2: max and
-        # add, no FMA to fuse).  SURVEY 8d's HBM model (20 B/cell) is reported as `algorithmic_hbm`:
-        # those bytes are LDS gathers in the query-lane kernel and L2 hits in the row sweep.
-        VALU_PEAK = 78.6e12
-        OPS_PER_CELL = 28
-        lane_ops = dom_cells * OPS_PER_CELL / (dom_ms * 1e-3)
-        # HBM bytes per launch of that kernel: PMC counters cannot be read inside this process, so the
-        # figure is REPLAYED from the committed rocprofv3 --pmc passes of this same command (see
-        # traffic_source); null when no matching profile is committed.
-        traffic, traffic_source = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_hbm.json")))
-            if pmc.get("workload") == args.workload and pmc.get("queries_per_step") == qstep and world == 1:
-                for pmc_name, pmc_entry in pmc["kernels"].items():
-                    if kname.split("<")[0] in pmc_name and "hbm_bytes_per_launch" in pmc_entry:
-                        traffic = pmc_entry["hbm_bytes_per_launch"]
-                        traffic_source = ("replayed (not measured in this run) from profiles/latest_pmc_hbm.json: "
-                                          + pmc.get("note", ""))
-        except (OSError, ValueError, KeyError):
-            pass
-        # What the VALU can do with THIS instruction mix: the row's arithmetic alone, measured in a registers-only
-        # microbenchmark (profiles/microbench/row_valu.hip; replayed like the PMC traffic).  28 ops per cell at
-        # the 2-cycle rate is not attainable for a max-plus recursion on gfx950: v_max_f32 / v_max3_f32 --
-        # a third of the ops -- and adds with an SGPR operand issue at half that rate (profiles/r03/valu_issue.txt).
-        valu_ceiling = None
-        try:
-            vc = json.load(open(os.path.join(ROOT, "profiles", "latest_valu_ceiling.json")))
-            cyc = float(vc["cycles_per_wavefront_row"])
-            at_spec = 256 * 4 * 64 * vc["nodes_per_lane"] / cyc * 2.4e9
-            valu_ceiling = {"cycles_per_wavefront_row_arithmetic_only": cyc,
-                            "gcells_per_s_at_2.4GHz": round(at_spec / 1e9, 1),
-                            "frac_of_ceiling": (round(dom_cells / (dom_ms * 1e-3) / at_spec, 4) if is_qlane else None),
-                            "source": "replayed from profiles/latest_valu_ceiling.json: " + vc["source"]}
-        except (OSError, ValueError, KeyError):
-            pass
-        # analytic HBM traffic of the design, to hold against the measured figure:
-        #   query lane: 12 B written + 12 B read per (row, lane, tile boundary) -- the Xm/Xd/Em planes --
-        #               plus every tile image once per (profile, 256-query block)
-        #   compulsory: SURVEY 8d note 2 -- 548*M + L + 8 bytes per pair (compact profile streamed once)
-        ntiles = (sizes[b:e].astype(np.int64) + 7) // 8
-        lanes = ((qstep // world + 63) // 64) * 64 if qlen else None
-        two_stage = sc.last_scan_kernel == dcp.KERNEL_QLANE2
-        hbm_boundaries = ((ntiles - 1) // 2) if two_stage else (ntiles - 1)  # odd -> even only / every boundary
-        scratch_bytes = (int(24 * int(hbm_boundaries.sum()) * lanes * qlen) if (is_qlane and qlen) else None)
-        tile_bytes = (int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep // world + 255) // 256) if is_qlane else None)
-        npairs_launch = (e - b) * (qstep // world)
-        compulsory = int(548 * int(sizes[b:e].sum()) * (qstep // world) + (qlen + 8) * npairs_launch) if qlen else None
-        roof = {
-            "bound": "valu-issue",
-            "kernel": kname,
-            "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK / 1e12, 1), "unit": "Tlane-op/s",
-            "frac": round(lane_ops / VALU_PEAK, 4),
-            "ops_per_cell": OPS_PER_CELL,
-            "valu_only_ceiling": valu_ceiling,
-            "peak_note": ("256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (spec clock); measured clock under this load: two-stage "
-                          "query-lane kernel 2.23 GHz, single-stage 1.81 GHz, row sweep 2.3-2.4 GHz (profiles/r02/*pmc*)"),
-            "avg_launch_ms": round(dom_ms, 3),
-            "cells_per_launch": int(dom_cells),
-            "gcells_per_s": round(dom_cells / (dom_ms * 1e-3) / 1e9, 1),
-            "traffic": traffic,
-            "traffic_source": traffic_source,
-            "hbm": {
-                "peak_gbs": 8000.0,
-                "measured_gbs": (round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None),
-                "measured_frac": (round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic else None),
-                "analytic_scratch_plane_bytes_per_launch": scratch_bytes,
-                "analytic_tile_image_bytes_per_launch": tile_bytes,
-                "compulsory_bytes_per_launch": compulsory,
-            },
-            # the row sweep reads SURVEY 8d's 20 B/cell of match emissions on chip: since round 3 the rows of the
-            # 1- and 2-base words (8 of the 20 B) from the block's LDS image, the other 12 B/cell from the XCD's L2
-            # (the profile's table is L2-resident while its queries run): against the L2 peak
-            # (MI355X_MICROARCH.md: 34.5 TB/s; its measured rate for gathering L2-resident rows is 16.8-18.8 TB/s)
-            "l2_gather": (None if is_qlane else {
-                "bytes_per_launch": int(dom_algo_bytes * 12 / 20),
-                "bytes_per_cell": 12,
-                "gbs": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 1e9, 1),
-                "peak_gbs": 34500.0,
-                "frac": round(dom_algo_bytes * 0.6 / (dom_ms * 1e-3) / 34.5e12, 3),
-                "lds_bytes_per_cell": 8,
-            }),
-            # SURVEY.md 8d's per-pair byte model 20*M*L + 32*(M+1) + L + 8: NOT a bound for this design
-            "algorithmic_hbm": {
-                "bytes_per_launch": int(dom_algo_bytes),
-                "gbs": round(dom_algo_bytes / (dom_ms * 1e-3) / 1e9, 1),
-                "ratio_to_hbm_peak": round(dom_algo_bytes / (dom_ms * 1e-3) / 8e12, 3),
-                "note": ("served from LDS: the 20 B/cell of match emissions are ds_read_b128 gathers from the "
-                         "LDS-resident tile image, never HBM reads -- a ratio above 1 is on-chip reuse, not a bound"
-                         if is_qlane else
-                         "served from L2/Infinity Cache: many queries re-read one profile's table rows"),
-            },
-            # where the query-lane kernel reads those bytes from: LDS, 256 B/clk/CU x 256 CUs x 2.4 GHz
-            # = 157 TB/s conflict-free (random 16-byte gathers serialise ~2.1x)
-            "lds": ({"bytes_per_cell": 20, "peak": 157286.0, "unit": "GB/s",
-                     "frac": round(dom_cells / (dom_ms * 1e-3) * 20 / 157.286e12, 4)} if is_qlane else None),
-            "kernel_ms_per_step": round(kernel_ms / args.steps, 3),
-            "per_class_ms_per_step": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"): round(v["ms"] / args.steps, 3)
-                                      for k, v in sorted(per_class.items())},
-            "per_class_gcells_per_s": {(f"R{k[0]}W{k[1]}" if k[1] else f"qlane_KT{k[0]}"):
-                                       round(v["cells"] / (v["ms"] * 1e-3) / 1e9, 1)
-                                       for k, v in sorted(per_class.items()) if v["cells"]},
-            # query-lane scans: pairs with multi-hit feedback are re-scored by the row-sweep
-            # launches (R*W* above) right after the query-lane kernel
-            "redo_pairs_per_step": round(redo_pairs / args.steps, 1),
-        }
+        roof = roofline_block(timed, dcp, args.workload, args.steps, sizes, b, e, qstep, world, qlen)
         out = {
             "metric": "Gcell-updates/sec",
             "value": round(cells_total / elapsed / 1e9, 3),
