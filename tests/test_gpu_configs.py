@@ -149,7 +149,6 @@ def test_c4_config_one_gpu_share_vs_unsharded(dcp, oracle32, bench_mod, c3_profi
         part.upload_seqs_flat(queries.reshape(-1), off)
         part.scan(True, False, 10.0, keep_scores=True)
         hp = part.hits()
-        assert part.launch_infos()[0]["W"] == 0  # the throughput kernel, as in the 8-GPU job
         want = hf[(hf["profile_idx"] >= b) & (hf["profile_idx"] < e)].copy()
         want["profile_idx"] -= b
         assert len(hp) > 100

@@ -363,11 +363,10 @@ def test_redo_pairs_of_multi_wavefront_classes(dcp, oracle32, scanner, M):
     assert {(1, 0), (4, 1)} <= got
 
 
-def test_kernel_choice_by_batch_size(dcp, scanner):
-    """kernel = 0 picks by a cost model: a DB of a few profiles cannot fill the query-lane kernel's
-    persistent grid, so it stays with the row sweep at any batch size (the 20k-profile DB switches to the
-    query-lane kernel at about 150 queries: test_full_size_c3_step_both_kernels_agree).  Forcing the other kernel
-    gives the same bits; launch infos tell the two apart."""
+def test_forced_kernels_give_the_automatic_choice_s_bits(dcp, scanner):
+    """Whatever kernel = 0 picks (a cost model: tests/test_zz_kernel_choice.py), forcing each kernel gives the same
+    bits; launch infos tell a query-lane scan (one W = 0 launch carrying all cells + redo launches carrying none)
+    from a row-sweep scan."""
     rng = np.random.default_rng(48)
     profiles = make_profiles(dcp, [(900 + i, int(m), ENTRY_DIST_OCCUPANCY, 0.01) for i, m in enumerate((3, 70, 130, 300))])
     seqs = rand_seqs(rng, 60, 20, 120)
@@ -376,15 +375,19 @@ def test_kernel_choice_by_batch_size(dcp, scanner):
     with pytest.raises(dcp.DcpError):
         dcp.Scanner(0).last_scan_redo_pairs  # no scan yet
     scanner.scan(True, False, 10.0)
-    assert all(li["W"] >= 1 for li in scanner.launch_infos())       # row-sweep launches only
-    assert scanner.last_scan_redo_pairs == 0
     n_auto, a_auto = scanner.scores()
-    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE)
-    infos = scanner.launch_infos()
-    assert infos[0]["W"] == 0 and infos[0]["cells"] == sum(p.core_size for p in profiles) * sum(len(s) for s in seqs)
-    assert all(li["cells"] == 0 for li in infos[1:])                 # redo launches carry no cells of their own
-    n_ql, a_ql = scanner.scores()
-    assert same_bits(n_auto, n_ql) and same_bits(a_auto, a_ql)
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+    assert all(li["W"] >= 1 for li in scanner.launch_infos())       # row-sweep launches only
+    assert scanner.last_scan_redo_pairs == 0 and scanner.last_scan_kernel == dcp.KERNEL_ROWSWEEP
+    n_rs, a_rs = scanner.scores()
+    assert same_bits(n_auto, n_rs) and same_bits(a_auto, a_rs)
+    for k in (dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2):
+        scanner.scan(True, False, 10.0, kernel=k)
+        infos = scanner.launch_infos()
+        assert infos[0]["W"] == 0 and infos[0]["cells"] == sum(p.core_size for p in profiles) * sum(len(s) for s in seqs)
+        assert all(li["cells"] == 0 for li in infos[1:])                 # redo launches carry no cells of their own
+        n_ql, a_ql = scanner.scores()
+        assert same_bits(n_auto, n_ql) and same_bits(a_auto, a_ql)
 
 
 def test_new_batch_of_equal_count_is_not_scanned_with_the_old_one_s_layout(dcp, scanner):
@@ -795,8 +798,9 @@ def test_more_than_65536_queries(dcp, oracle32, scanner, kern):
 
 def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
     """The reference accepts sequences up to SCHED_SEQ_SIZE = 1 MiB (src/server/scan.c:227-229 reads them into a
-    buffer of that size).  A 300 000-nt query: the automatic choice is the row sweep (the query-lane kernels would
-    keep one lane busy for minutes); forced, the query-lane kernels hold too -- 32-bit row offsets into scratch
+    buffer of that size).  A 300 000-nt query: the automatic choice (the row sweep -- the query-lane kernels would
+    keep one lane busy for minutes; asserted in tests/test_zz_kernel_choice.py), and every kernel forced: the
+    query-lane kernels hold too -- 32-bit row offsets into scratch
     planes of 300 MB, fewer resident blocks.  All equal the oracle bit for bit."""
     rng = np.random.default_rng(1 << 20)
     profiles = make_profiles(dcp, [(301, 40, ENTRY_DIST_OCCUPANCY, 0.01), (302, 120, ENTRY_DIST_OCCUPANCY, 0.01)])
@@ -804,9 +808,7 @@ def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
     scanner.upload_db(profiles, expand_on_host=True)
     scanner.upload_seqs(seqs)
     on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
-    scanner.scan(True, False, 10.0)
-    assert scanner.last_scan_kernel == dcp.KERNEL_ROWSWEEP
-    for k in (dcp.KERNEL_AUTO, dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2):
+    for k in (dcp.KERNEL_AUTO, dcp.KERNEL_ROWSWEEP, dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2):
         scanner.scan(True, False, 10.0, kernel=k)
         gn, ga = scanner.scores()
         assert same_bits(gn, on) and same_bits(ga, oa), k
@@ -816,7 +818,6 @@ def test_sequence_near_the_scheduler_limit(dcp, oracle32, scanner):
     scanner.upload_seqs(seqs)
     on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, True)
     scanner.scan(True, False, 10.0)
-    assert scanner.last_scan_kernel == dcp.KERNEL_ROWSWEEP
     gn, ga = scanner.scores()
     assert same_bits(gn, on) and same_bits(ga, oa)
 
@@ -841,17 +842,11 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
             if name == "qlane":
                 redo = sc.last_scan_redo_pairs
         assert 0 < redo < 0.05 * 2e7
-        # kernel = 0 on this DB: the row sweep up to about 150 queries (128 queries: 450 ms against 479 ms),
-        # the single-stage query-lane kernel from there, the two-stage one once the blocks are mostly full
-        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 16))
-        assert sc.launch_infos()[0]["W"] >= 1 and sc.last_scan_kernel == dcp.KERNEL_ROWSWEEP
-        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 64))
-        assert sc.launch_infos()[0]["W"] >= 1 and sc.last_scan_kernel == dcp.KERNEL_ROWSWEEP
-        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 160))
-        assert sc.launch_infos()[0]["W"] == 0 and sc.last_scan_kernel == dcp.KERNEL_QLANE
-        sc.scan(True, False, 10.0, keep_scores=False, q_range=(0, 1000))
-        assert sc.last_scan_kernel == dcp.KERNEL_QLANE2
-        for other in ("qlane2", "rowsweep"):
+        # (what kernel = 0 picks on this DB at which batch size is a tuning matter: tests/test_zz_kernel_choice.py)
+        sc.scan(True, False, 10.0, kernel=dcp.KERNEL_AUTO)
+        n, a = sc.scores()
+        out["auto"] = (n.view(np.uint32).copy(), a.view(np.uint32).copy(), sc.hits())
+        for other in ("qlane2", "rowsweep", "auto"):
             assert np.array_equal(out["qlane"][0], out[other][0]), other
             assert np.array_equal(out["qlane"][1], out[other][1]), other
             assert np.array_equal(out["qlane"][2], out[other][2]), other
