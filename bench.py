@@ -204,15 +204,33 @@ def parity_sample(dcp, sc, sizes, shard_begin, qlen, q_range, nsample=48):
     return {"pairs": n, "max_rel_err_vs_oracle": float("%.3g" % worst), "tolerance": 5e-5, "ok": bool(worst <= 5e-5)}
 
 
+def profiler_preload():
+    """A profiler's preloaded library (rocprofv3 and friends) initialises the GPU in THIS process before main()
+    runs; starting rank children from such a process is the exec-after-HIP-init hop this pool forbids.  Returns
+    what gives the preload away, or None."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if any(k in pre for k in ("rocprof", "roctracer", "rocprofiler")):
+        return "LD_PRELOAD=" + pre
+    for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"):
+        if os.environ.get(k):
+            return k + "=" + os.environ[k]
+    return None
+
+
 def self_launch(argv, ngpus, grace_s=20.0):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.
 
-    The parent never touches the GPU (it imports neither torch nor the product library): the ranks are
-    plain child processes -- never an exec of a process that initialised HIP -- with RANK, LOCAL_RANK,
-    WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT in their environment, exactly what
-    torch.distributed.run would give them.  Rank 0 inherits stdout (its one JSON line is the parent's
-    output), the other ranks' stdout goes to stderr.  Returns the first non-zero child return code (a
-    failed rank leaves the others blocked in a collective: they are given `grace_s`, then terminated by PID)."""
+    The parent imports neither torch nor the product library and makes no HIP call: the ranks are plain child
+    processes -- never an exec of a process that initialised HIP -- with RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR=127.0.0.1 and a free MASTER_PORT in their environment, exactly what torch.distributed.run
+    would give them.  (Under a profiler that is not true -- its preload touches the GPU in the parent -- so
+    main() refuses to self-launch there: profile ONE rank directly, `rocprofv3 ... -- python3 bench.py --gpus 1`,
+    or run the profiler under torch.distributed.run.)  Rank 0 inherits stdout (its one JSON line is the
+    parent's output), the other ranks' stdout goes to stderr.  Returns the first non-zero child return code (a
+    failed rank leaves the others blocked in a collective: they are given `grace_s`, then terminated by PID).
+    If the parent itself is told to stop (SIGTERM from `timeout`, Ctrl-C) or dies on an exception, exactly
+    the PIDs started here are terminated, waited for, then killed: no rank is left holding a GPU in a collective."""
+    import signal
     import socket
     import subprocess
 
@@ -220,34 +238,101 @@ def self_launch(argv, ngpus, grace_s=20.0):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
-    for r in range(ngpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   DCP_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc, deadline = 0, None
-    alive = list(procs)
-    while alive:
-        for pr in list(alive):
-            code = pr.poll()
-            if code is None:
-                continue
-            alive.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 128 - code
-                deadline = time.monotonic() + grace_s
-        if deadline is not None and alive and time.monotonic() > deadline:
-            for pr in alive:
-                pr.terminate()  # exactly the PIDs started above
-            for pr in alive:
-                try:
-                    pr.wait(10)
-                except subprocess.TimeoutExpired:
-                    pr.kill()
-            break
-        time.sleep(0.05)
+
+    def reap(alive):
+        for pr in alive:
+            if pr.poll() is None:
+                pr.terminate()  # exactly the PIDs started below
+        for pr in alive:
+            try:
+                pr.wait(10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+
+    class Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise Stopped(signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    rc = 0
+    try:
+        for r in range(ngpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       DCP_BENCH_SELF_LAUNCHED="1", DCP_BENCH_PARENT_PID=str(os.getpid()))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        deadline = None
+        alive = list(procs)
+        while alive:
+            for pr in list(alive):
+                code = pr.poll()
+                if code is None:
+                    continue
+                alive.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    deadline = time.monotonic() + grace_s
+            if deadline is not None and alive and time.monotonic() > deadline:
+                break
+            time.sleep(0.05)
+    except Stopped as st:
+        rc = 128 + int(st.args[0])
+    finally:
+        for sig in old:
+            signal.signal(sig, signal.SIG_IGN)  # a second signal must not interrupt the clean-up
+        reap([pr for pr in procs if pr.poll() is None])
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
+
+
+def die_with_parent():
+    """A self-launched rank asks the kernel for SIGTERM when its launcher dies (PR_SET_PDEATHSIG): a parent killed
+    with SIGKILL cannot run its clean-up, and the ranks would stay blocked in a collective holding the GPUs."""
+    ppid = os.environ.get("DCP_BENCH_PARENT_PID")
+    if not ppid:
+        return
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG = 1
+        if os.getppid() != int(ppid):  # the launcher died before the prctl took effect
+            sys.exit(143)
+    except (OSError, AttributeError, ValueError):
+        pass
+
+
+def multi_gpu_block(dist, torch, device, rank, world, mine, transport, rccl_comm_count):
+    """N > 1 diagnostics for the JSON line: every rank contributes
+    [timed-leg seconds, cells scanned, shard begin, shard end, sum M of the shard, gather seconds, kernel ms,
+     ranks its RCCL communicator reports]; rank 0 prints per-rank rows, min / max / imbalance and the transport.
+    One all_gather of 8 doubles after the timed region."""
+    v = torch.tensor([float(x) for x in mine], dtype=torch.float64, device=device)
+    allv = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(allv, v)
+    rows = [t.cpu().tolist() for t in allv]
+    if rank != 0:
+        return None
+    steps = max(1.0, rows[0][7])
+    per_rank = [{"rank": r, "ms_per_step": round(x[0] / steps * 1e3, 3), "cells": int(x[1]),
+                 "shard": [int(x[2]), int(x[3])], "shard_sum_m": int(x[4]),
+                 "gather_ms_per_step": round(x[5] / steps * 1e3, 3),
+                 "kernel_ms_per_step": round(x[6] / steps, 3),
+                 "rccl_comm_count": int(rows[r][8]) if len(x) > 8 else None} for r, x in enumerate(rows)]
+    ms = [p["ms_per_step"] for p in per_rank]
+    sm = [p["shard_sum_m"] for p in per_rank]
+    tiles = all(per_rank[r]["shard"][1] == per_rank[r + 1]["shard"][0] for r in range(world - 1)) and per_rank[0]["shard"][0] == 0
+    return {"ranks": world, "transport": transport,
+            "rccl_comm_count": rccl_comm_count,  # ncclCommCount of the C library's communicator on rank 0 (None: not in use)
+            "shards_tile_the_db": bool(tiles),
+            "sum_m_imbalance": round(max(sm) / (sum(sm) / world) - 1.0, 5) if sum(sm) else None,
+            "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+            "time_imbalance": round(max(ms) / (sum(ms) / world) - 1.0, 5) if sum(ms) else None,
+            "per_rank": per_rank}
 
 
 def stub_rank(args, rank, world):
@@ -270,6 +355,9 @@ def stub_rank(args, rank, world):
     b, e = ddist.shard_range(sizes, world, rank)
     if args.stub_fail_rank == rank:
         sys.exit(7)  # rc propagation through the launcher
+    piddir = os.environ.get("DCP_BENCH_STUB_PIDDIR")
+    if piddir:  # the launcher clean-up test wants to know which PIDs to look for afterwards
+        open(os.path.join(piddir, "rank%d.pid" % rank), "w").write(str(os.getpid()))
     cap = 64
     words = torch.zeros((cap, 4), dtype=torch.int32)
     count = torch.zeros(1, dtype=torch.int32)
@@ -286,28 +374,40 @@ def stub_rank(args, rank, world):
         if n:
             words[:n] = torch.from_numpy(rec.view(np.int32).reshape(n, 4))
         count[0] = n
+        if args.stub_sleep:
+            time.sleep(args.stub_sleep)
+        tg = time.perf_counter()
         h = ddist.gather_hits(words, count, b)
+        gather_s[0] += time.perf_counter() - tg
         assert len(h) == sum((i + r) % 5 for r in range(world))
         assert (np.diff(h["seq_idx"].astype(np.int64)) >= 0).all() and (h["profile_idx"] < nprof).all()
         seen += len(h)
 
+    gather_s = [0.0]
     for i in range(args.warmup):
         step(i)
     dist.barrier()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    mine_s = time.perf_counter() - t0
     dist.barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     bounds = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(bounds, torch.tensor([b, e]))
+    sum_m = int(sizes[b:e].sum())
+    mg = multi_gpu_block(dist, torch, "cpu", rank, world,
+                         [mine_s, float(sum_m) * qstep * 1000 * args.steps, b, e, sum_m, gather_s[0], 0.0, args.steps, -1],
+                         "gloo + dcp_dist_merge_hits (stub)", None)
     if rank == 0:
         print(json.dumps({"metric": "STUB (launcher test: no scan ran, nothing was measured)", "value": 0.0,
                           "unit": "Gcell/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 3),
                           "stub": True, "transport": "gloo + dcp_dist_merge_hits",
                           "shards": [[int(x) for x in t] for t in bounds], "hits_gathered": seen,
+                          "multi_gpu": mg,
                           "self_launched": os.environ.get("DCP_BENCH_SELF_LAUNCHED") == "1"}))
     dist.barrier()
     dist.destroy_process_group()
@@ -322,6 +422,7 @@ class TimedLeg:
         self.redo_pairs = 0
         self.kernels = {}        # dcp_gpu_last_scan_kernel of every timed step -> steps
         self.elapsed = 0.0
+        self.elapsed_rank = 0.0
 
     @property
     def kernel(self):
@@ -346,6 +447,7 @@ def timed_leg(sc, step, first, last, fence):
         cap.redo_pairs += sc.last_scan_redo_pairs
         kid = sc.last_scan_kernel
         cap.kernels[kid] = cap.kernels.get(kid, 0) + 1
+    cap.elapsed_rank = time.perf_counter() - t0  # this rank's own steps, before it waits for the others
     fence()
     cap.elapsed = time.perf_counter() - t0
     return cap
@@ -535,12 +637,21 @@ def main():
                          "to the host); default min(steps, 5), 0 = skip")
     ap.add_argument("--stub-scan", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU (gloo)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--stub-sleep", type=float, default=0.0, help=argparse.SUPPRESS)  # seconds per stub step
     ap.add_argument("--launch-grace", type=float, default=20.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process only starts and reaps the N ranks
+        why = profiler_preload()
+        if why:
+            sys.stderr.write("bench.py: refusing to start %d rank processes from a process a profiler has preloaded "
+                             "(%s): its library initialises the GPU here, and a child started from a GPU-initialised "
+                             "process is forbidden on this pool.  Profile one rank directly (`--gpus 1`), or put the "
+                             "profiler under torch.distributed.run.\n" % (args.gpus, why))
+            sys.exit(2)
         sys.exit(self_launch(sys.argv[1:], args.gpus, args.launch_grace))
+    die_with_parent()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -666,10 +777,13 @@ def main():
 
     cdist_state = {"comm": cdist, "kind": gather_kind}
 
+    gather_s = [0.0]
+
     def step(i):
         sc.scan(True, False, 10.0, keep_scores=False, sync=False, q_range=(i * qstep, (i + 1) * qstep),
                 kernel=kernel_id)
         sc.sync()
+        tg = time.perf_counter()
         if cdist_state["comm"]:
             h, total = cdist_state["comm"].gather_scan_hits(sc, b)
             if i < args.warmup:
@@ -688,6 +802,7 @@ def main():
             h = ddist.gather_hits(hit_words, hit_count, b)
         else:
             h = None
+        gather_s[0] += time.perf_counter() - tg
         if args.planted:  # a few hundred records: negligible beside the scan
             if h is None:
                 rec = hit_words[:int(hit_count.item())].cpu().numpy()
@@ -705,6 +820,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    gather_s[0] = 0.0
     # everything the roofline block says about "the dominant kernel" is captured HERE, inside the timed leg: the
     # later legs (e2e, small batches, parity sample) scan on the same context and move sc.last_scan_kernel
     timed = timed_leg(sc, step, args.warmup, nsteps, fence)
@@ -761,6 +877,15 @@ def main():
     if world == 1 and not force_dist and not args.dense and not args.stub_scan and args.kernel == "auto":
         small = small_batches_leg(sc, dcp, small_src, qlen, float(sizes[b:e].sum()),
                                   lambda: hit_words[:min(cap, int(hit_count.item()))].cpu().numpy())
+    multi_gpu = None
+    if world > 1 or force_dist:
+        # per-rank figures of the timed leg BEFORE the max-over-ranks reduction hides them: a slow rank, an uneven
+        # shard or a slow gather must be readable from the one JSON line of a run nobody can repeat by hand
+        comm_count = cdist_state["comm"].comm_count if cdist_state["comm"] else -1
+        multi_gpu = multi_gpu_block(dist, torch, "cuda", rank, world,
+                                    [timed.elapsed_rank, cells_rank, b, e, int(sizes[b:e].sum()), gather_s[0],
+                                     kernel_ms, args.steps, comm_count],
+                                    cdist_state["kind"], comm_count if cdist_state["comm"] else None)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -796,6 +921,7 @@ def main():
                 "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({cdist_state['kind']})" if (world > 1 or force_dist) else ""),
             },
             "roofline": roof,
+            "multi_gpu": multi_gpu,
             "e2e": e2e,
             "small_batches": small,
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},

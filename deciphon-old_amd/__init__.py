@@ -49,7 +49,8 @@ ABI_SYMBOLS = [
     "dcp_profile_from_parts", "dcp_profile_entry_dist", "dcp_profile_epsilon", "dcp_rnd_seed", "dcp_rnd_next",
     "dcp_dist_unique_id", "dcp_dist_init", "dcp_dist_init_from_file", "dcp_dist_free", "dcp_dist_rank",
     "dcp_dist_nranks", "dcp_dist_last_error", "dcp_dist_shard", "dcp_dist_gather_hits", "dcp_dist_free_hits",
-    "dcp_dist_merge_hits", "dcp_dist_gather_scan_hits", "dcp_dist_gather_plan",
+    "dcp_dist_merge_hits", "dcp_dist_gather_scan_hits", "dcp_dist_gather_plan", "dcp_dist_init_from_file_run",
+    "dcp_dist_comm_count", "dcp_dist_last_gather_ms",
     "dcp_lprob_normalize", "dcp_h3reader_open_fp", "dcp_h3reader_next_params", "dcp_gpu_seqs_set_xtrans",
     "dcp_profile_accession", "dcp_profile_trans8", "dcp_profile_null_dist",
     "dcp_profile_insert_dist", "dcp_profile_match_dist", "dcp_frame_table_host", "dcp_xtrans",

@@ -43,7 +43,13 @@ def bind(lib):
                                               C.POINTER(C.c_uint)]
     lib.dcp_dist_gather_plan.restype = C.c_int
     lib.dcp_dist_gather_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
-                                         C.POINTER(C.c_uint64)]
+                                         C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    lib.dcp_dist_init_from_file_run.restype = C.c_void_p
+    lib.dcp_dist_init_from_file_run.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.dcp_dist_comm_count.restype = C.c_int
+    lib.dcp_dist_comm_count.argtypes = [C.c_void_p]
+    lib.dcp_dist_last_gather_ms.restype = C.c_double
+    lib.dcp_dist_last_gather_ms.argtypes = [C.c_void_p]
     lib.dcp_dist_free_hits.restype = None
     lib.dcp_dist_free_hits.argtypes = [C.c_void_p]
     lib.dcp_dist_merge_hits.restype = C.c_long
@@ -87,19 +93,25 @@ def merge_hits(counts, profile_offsets, records):
 
 
 META_WORDS = 3  # DCP_DIST_META_WORDS: records held, profile offset, records found
+FOUND_FAILED = 0xFFFFFFFF  # DCP_DIST_FOUND_FAILED: "records found" of a rank whose scan failed
 
 
-def gather_plan(meta):
-    """dcp_dist_gather_plan: meta [nranks, 3] uint32 -> (counts, offsets, displ[nranks+1] uint64, any_overflow, total).
-    Raises DcpError(EINVAL) when the total exceeds 2^32 - 1 or a rank holds more than it found."""
+def gather_plan(meta, with_failed=False):
+    """dcp_dist_gather_plan: meta [nranks, 3] uint32 -> (counts, offsets, displ[nranks+1] uint64, any_overflow, total)
+    (+ any_failed as a sixth item when with_failed).  Raises DcpError(EINVAL) when the total exceeds 2^32 - 1 or a
+    rank holds more than it found."""
     m = np.ascontiguousarray(meta, np.uint32).reshape(-1, META_WORDS)
     n = len(m)
     counts, offs, displ = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n + 1, np.uint64)
-    ovf, total = C.c_int(0), C.c_uint64(0)
+    ovf, failed, total = C.c_int(0), C.c_int(0), C.c_uint64(0)
     rc = lib.dcp_dist_gather_plan(m.ctypes.data, n, counts.ctypes.data, offs.ctypes.data, displ.ctypes.data,
-                                  C.byref(ovf), C.byref(total))
+                                  C.byref(ovf), C.byref(failed), C.byref(total))
     if rc:
         raise DcpError(rc, "dcp_dist_gather_plan")
+    if with_failed:
+        return counts, offs, displ, bool(ovf.value), int(total.value), bool(failed.value)
+    if failed.value:
+        raise DcpError(RC_EFAIL, "a rank's scan failed: its shard's hits are missing from the gathered list")
     return counts, offs, displ, bool(ovf.value), int(total.value)
 
 
@@ -153,6 +165,15 @@ class CDist:
             return arr[:n.value * HIT_WORDS].copy().view(HIT_DTYPE), n.value
         finally:
             self._lib.dcp_dist_free_hits(out)
+
+    @property
+    def comm_count(self):
+        """Ranks RCCL itself reports for the communicator (ncclCommCount)."""
+        return self._lib.dcp_dist_comm_count(self._h)
+
+    @property
+    def last_gather_ms(self):
+        return self._lib.dcp_dist_last_gather_ms(self._h)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -407,18 +407,29 @@ char const *dcp_prod_header(void);
 typedef struct dcp_dist dcp_dist;
 enum { DCP_DIST_ID_BYTES = 128 }; /* NCCL_UNIQUE_ID_BYTES */
 enum { DCP_DIST_META_WORDS = 3 }; /* per rank in the meta all-gather: records held, profile offset, records found */
+/* "records found" of a rank whose scan FAILED (it holds 0 records): not a count, a status every rank reads */
+#define DCP_DIST_FOUND_FAILED 0xFFFFFFFFu
 /* Rank 0 creates the communicator id (ncclGetUniqueId) and hands it to the other ranks through
  * whatever channel the launcher has (bench.py: torch.distributed; a C launcher: the file variant). */
 int dcp_dist_unique_id(unsigned char id[DCP_DIST_ID_BYTES]);
 dcp_dist *dcp_dist_init(unsigned char const id[DCP_DIST_ID_BYTES], int rank, int nranks, int device);
 /* Rendezvous through a file: rank 0 writes the id to `path`, the others wait up to timeout_s for it.
- * `path` must be FRESH for every run (e.g. carry the launcher's pid): rank 0 removes what lies there
- * before creating its id, and the other ranks refuse a file of another layout or rank count or one written
- * more than 120 s before they arrived -- ranks with different ids would block in ncclCommInitRank. */
+ * Ranks holding different ids would block in ncclCommInitRank, so a peer must tell this run's file from a
+ * left-over one.  _run: the launcher gives every rank the same non-zero `run_nonce` (its pid and start time,
+ * say); rank 0 writes it into the file and a peer takes ONLY a file carrying it -- safe for back-to-back runs
+ * at one path.  Without a nonce (the second form = run_nonce 0) `path` must be FRESH for every run: rank 0
+ * removes what lies there before creating its id, and the other ranks refuse a file of another layout or rank
+ * count or one written more than 120 s before they arrived. */
+dcp_dist *dcp_dist_init_from_file_run(char const *path, uint64_t run_nonce, int rank, int nranks, int device,
+                                      double timeout_s);
 dcp_dist *dcp_dist_init_from_file(char const *path, int rank, int nranks, int device, double timeout_s);
 void dcp_dist_free(dcp_dist *);
 int dcp_dist_rank(dcp_dist const *);
 int dcp_dist_nranks(dcp_dist const *);
+/* Diagnostics for the launcher: the rank count RCCL itself reports for the communicator (ncclCommCount; must
+ * equal dcp_dist_nranks; -1 without one), and the wall time of this rank's last gather in ms. */
+int dcp_dist_comm_count(dcp_dist const *);
+double dcp_dist_last_gather_ms(dcp_dist const *);
 char const *dcp_dist_last_error(dcp_dist const *);
 /* [begin, end) of rank's shard: dcp_partition_by_cells over nranks. */
 void dcp_dist_shard(unsigned const *core_sizes, unsigned nprofiles, int nranks, int rank, unsigned *begin,
@@ -433,8 +444,11 @@ void dcp_dist_shard(unsigned const *core_sizes, unsigned nprofiles, int nranks, 
  * profile indices, ordered by (seq_idx, profile_idx); elsewhere *out = NULL and *nout = the global total.
  * If ANY rank's scan found more hits than its buffer holds, every rank still completes both exchanges
  * with the records there are (nobody is left waiting) and then EVERY rank returns DCP_ENOMEM -- on a
- * receiving rank with *out set to the incomplete list.  A rank whose scan failed takes part with an
- * empty list and returns its scan's error.  More than 2^32 - 1 records in all: DCP_EINVAL everywhere. */
+ * receiving rank with *out set to the incomplete list.  A rank whose scan FAILED (dcp_gpu_sync /
+ * dcp_gpu_hit_buffer returned an error) takes part in both exchanges holding nothing and marks its meta
+ * words (found = DCP_DIST_FOUND_FAILED): it returns its scan's error, and EVERY other rank returns DCP_EFAIL
+ * -- a root never gets DCP_OK for a list that lacks one shard's hits (*out, if set, is that incomplete list;
+ * free it).  More than 2^32 - 1 records in all: DCP_EINVAL everywhere. */
 int dcp_dist_gather_scan_hits(dcp_dist *, dcp_gpu_ctx *ctx, unsigned profile_offset, int root,
                               struct dcp_hit **out, unsigned *nout);
 /* The same for an explicit device buffer (hits_dev / nhits_dev / cap as given to dcp_gpu_set_hit_buffer).
@@ -444,10 +458,11 @@ int dcp_dist_gather_hits(dcp_dist *, void const *hits_dev, void const *nhits_dev
                          unsigned profile_offset, int root, void *scan_stream, struct dcp_hit **out,
                          unsigned *nout);
 /* What every rank derives from the gathered meta words ({held, profile_offset, found} x nranks): counts,
- * offsets, 64-bit displacements displ[nranks + 1], whether any rank overflowed, the total.  Host only.
+ * offsets, 64-bit displacements displ[nranks + 1], whether any rank overflowed (found > held), whether any
+ * rank's scan failed (found = DCP_DIST_FOUND_FAILED, held = 0), the total.  Host only.
  * DCP_EINVAL when the total exceeds 2^32 - 1 or a rank holds more than it found. */
 int dcp_dist_gather_plan(uint32_t const *meta, int nranks, unsigned *counts, unsigned *profile_offset,
-                         uint64_t *displ, int *any_overflow, uint64_t *total);
+                         uint64_t *displ, int *any_overflow, int *any_failed, uint64_t *total);
 void dcp_dist_free_hits(struct dcp_hit *hits);
 /* The bookkeeping of the gather alone (host, no device, no RCCL): counts[r] records of rank r lie back
  * to back in `records`; out receives them with profile_idx += profile_offset[r], ordered by

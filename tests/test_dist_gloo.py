@@ -119,6 +119,30 @@ def test_gather_plan_bookkeeping(dcp):
         ddist.gather_plan([[5, 0, 4]])
 
 
+def test_gather_plan_tells_a_failed_scan_from_no_hits(dcp):
+    """a rank whose scan failed used to join the gather with {0, off, 0} -- "no hits" -- and every other
+    rank, a receiving root included, returned DCP_OK with a list that silently lacked one shard.  It now marks its
+    meta words (found = DCP_DIST_FOUND_FAILED, held = 0) and the plan every rank derives says any_failed."""
+    from deciphon_old_amd import dist as ddist
+
+    F = ddist.FOUND_FAILED
+    assert F == 0xFFFFFFFF
+    counts, offs, displ, ovf, total, failed = ddist.gather_plan([[3, 0, 3], [0, 70, 0], [5, 90, 5]], with_failed=True)
+    assert not failed and not ovf and total == 8
+    counts, offs, displ, ovf, total, failed = ddist.gather_plan([[3, 0, 3], [0, 70, F], [5, 90, 5]], with_failed=True)
+    assert failed and not ovf           # a failure is not an overflow (held 0 < found)
+    assert list(counts) == [3, 0, 5] and list(displ) == [0, 3, 3, 8] and total == 8  # the exchange still completes
+    # failure and overflow on different ranks: both are seen
+    *_, ovf, total, failed = ddist.gather_plan([[2, 0, 7], [0, 50, F]], with_failed=True)
+    assert failed and ovf and total == 2
+    # a failed rank holds nothing
+    with pytest.raises(dcp.DcpError):
+        ddist.gather_plan([[1, 0, F]], with_failed=True)
+    # the torch.distributed transport's use of the plan raises on a failed rank too
+    with pytest.raises(dcp.DcpError):
+        ddist.gather_plan([[3, 0, 3], [0, 70, F]])
+
+
 def test_id_file_must_be_fresh(dcp, tmp_path):
     """dcp_dist_init_from_file, rank > 0: a left-over file (old layout, another rank count, or older than
     the staleness bound) is refused -- the call times out instead of joining a communicator of its own
@@ -134,14 +158,28 @@ def test_id_file_must_be_fresh(dcp, tmp_path):
     t0 = time.time()
     assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
     assert time.time() - t0 < 5
-    path.write_bytes(struct.pack("<II", 0xDC9D1573, 4) + bytes(128))  # a run with 4 ranks, we are one of 2
+    path.write_bytes(struct.pack("<II", 0xDC9D1573, 2) + bytes(128))  # round 3's layout (no nonce field)
     assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
-    path.write_bytes(struct.pack("<II", 0xDC9D1573, 2) + bytes(128))  # right layout, written long ago
+    path.write_bytes(struct.pack("<IIQ", 0xDC9D1574, 4, 0) + bytes(128))  # a run with 4 ranks, we are one of 2
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
+    path.write_bytes(struct.pack("<IIQ", 0xDC9D1574, 2, 0) + bytes(128))  # right layout, written long ago
     old = time.time() - 3600
     os.utime(path, (old, old))
     assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
     assert not lib.dcp_dist_init_from_file(None, 0, 1, 0, 0.1)
     assert not lib.dcp_dist_init_from_file(str(path).encode(), 2, 2, 0, 0.1)  # rank out of range
+    # with a run nonce a YOUNG left-over file of a previous run (same path, same rank count) is not
+    # taken either -- a peer that arrives before rank 0 has replaced it waits for this run's nonce
+    ddist.bind(lib)
+    path.write_bytes(struct.pack("<IIQ", 0xDC9D1574, 2, 1111) + bytes(128))  # previous run, written just now
+    t0 = time.time()
+    assert not lib.dcp_dist_init_from_file_run(str(path).encode(), 2222, 1, 2, 0, 0.3)
+    assert time.time() - t0 < 5
+    path.write_bytes(struct.pack("<IIQ", 0xDC9D1574, 2, 0) + bytes(128))     # a nonce-less run's file
+    assert not lib.dcp_dist_init_from_file_run(str(path).encode(), 2222, 1, 2, 0, 0.3)
+    # and a nonce-less peer does not take a nonce-carrying run's file
+    path.write_bytes(struct.pack("<IIQ", 0xDC9D1574, 2, 1111) + bytes(128))
+    assert not lib.dcp_dist_init_from_file(str(path).encode(), 1, 2, 0, 0.3)
 
 
 def _gpu_worker(rank, world, port, tmpdir):
@@ -248,6 +286,19 @@ def test_c_rccl_gather_one_rank(dcp):
         # without a caller buffer the context's own one is gathered
         sc.scan(True, False, 10.0, sync=False)
         got, _ = comm.gather_scan_hits(sc, 0)
+        assert np.array_equal(got, want)
+        assert comm.comm_count == 1 and comm.last_gather_ms > 0.0  # what RCCL itself says; the launcher's diagnostics
+        # a rank with no valid scan (here: a context that never scanned) still completes both exchanges -- marked
+        # DCP_DIST_FOUND_FAILED, holding nothing -- and returns ITS error (what its peers return is
+        # test_gather_plan_tells_a_failed_scan_from_no_hits)
+        never = dcp.Scanner(0)
+        try:
+            with pytest.raises(dcp.DcpError) as ei:
+                comm.gather_scan_hits(never, 0)
+            assert ei.value.rc == dcp.RC_EINVAL and "no scan yet" in str(ei.value)
+        finally:
+            never.close()
+        got, _ = comm.gather_scan_hits(sc, 0)  # the communicator is still usable
         assert np.array_equal(got, want)
     finally:
         comm.close()
