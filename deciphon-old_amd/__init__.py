@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "dcp_dist_unique_id", "dcp_dist_init", "dcp_dist_init_from_file", "dcp_dist_free", "dcp_dist_rank",
     "dcp_dist_nranks", "dcp_dist_last_error", "dcp_dist_shard", "dcp_dist_gather_hits", "dcp_dist_free_hits",
     "dcp_dist_merge_hits", "dcp_dist_gather_scan_hits", "dcp_dist_gather_plan", "dcp_dist_init_from_file_run",
-    "dcp_dist_comm_count", "dcp_dist_last_gather_ms",
+    "dcp_dist_comm_count", "dcp_dist_last_gather_ms", "dcp_plan_query_slots",
     "dcp_lprob_normalize", "dcp_h3reader_open_fp", "dcp_h3reader_next_params", "dcp_gpu_seqs_set_xtrans",
     "dcp_profile_accession", "dcp_profile_trans8", "dcp_profile_null_dist",
     "dcp_profile_insert_dist", "dcp_profile_match_dist", "dcp_frame_table_host", "dcp_xtrans",
@@ -179,6 +179,7 @@ def _load(path=None, hooks=False):
     if hooks:
         sig["dcp_gpu_test_set_redo_cap"] = (I, [P, U])
         sig["dcp_gpu_test_set_rowsweep_variant"] = (I, [P, I, U])
+        sig["dcp_gpu_test_set_ring_stall"] = (I, [P, I])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -562,6 +563,11 @@ class Scanner:
         """TEST-ONLY, and only on a Scanner of the test-hooks build (load_testhooks): shrink the redo lists
         (0 restores 2^26) to reach the overflow path."""
         self._check(self._lib.dcp_gpu_test_set_redo_cap(self._c, int(cap)))
+
+    def test_set_ring_stall(self, on):
+        """TEST-ONLY (test-hooks build): the next two-stage query-lane scans stall one stage of the first task, so its
+        partner runs into the ring hand-shake's poll bound (the scan must fail with RC_EFAIL, not hang)."""
+        self._check(self._lib.dcp_gpu_test_set_ring_stall(self._c, int(bool(on))))
 
     def test_set_rowsweep_variant(self, stage_rows, block_waves=0):
         """TEST-ONLY (test-hooks build): force the grid-mode row-sweep kernel variant; stage_rows < 0: automatic."""

@@ -18,6 +18,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <queue>
 #include <vector>
 
 namespace
@@ -107,7 +108,12 @@ struct dcp_gpu_ctx
     DevBuf<dcp_ql_prof> d_ql_metas;
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
-    DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block sequence planes (row windows, or packed words)
+    DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block window planes
+    DevBuf<dcp_ql_group> d_ql_groups;     // groups of up to 64 queries and the wavefront slots they are packed into
+    DevBuf<uint32_t> d_slot_first;
+    unsigned ql_nqb = 0, ql_plane_rows = 0; // the cached plan: blocks of slots, rows of a block's scratch planes
+    unsigned ring_stall = 0;                // test hook: dcp_qlane_args::ring_stall
+    bool ring_check_pending = false;        // a two-stage scan's error word has not been looked at yet
     // the length-sorted query order and the plane offsets travel through pinned host memory: the copies are
     // truly asynchronous and dcp_gpu_scan_range returns without waiting for the stream
     uint32_t *h_qstage = nullptr;
@@ -121,7 +127,7 @@ struct dcp_gpu_ctx
     bool any_exact_e = false;             // some profile has a positive MD / DD (dcp_ql_prof::needs_exact_e)
     DevBuf<unsigned> d_task_counter;
     // redo lists of the query-lane kernel (pairs handed to the row sweep), one per size class;
-    // d_redo_n = [DCP_MAX_CLASSES counters][overflow flag]
+    // d_redo_n = [DCP_MAX_CLASSES counters][overflow flag][ring hand-shake error word]
     DevBuf<dcp_pair> d_redo;
     DevBuf<unsigned> d_redo_n;
     bool redo_pending = false;      // the last scan's redo counters have not been checked yet
@@ -691,6 +697,7 @@ static int upload_seqs(dcp_gpu_ctx *c, uint8_t const *seqs, uint32_t const *seq_
     HIP_TRY(c, hipSetDevice(c->device));
     c->scanned = false;
     c->redo_pending = false;           // the previous batch's scan is void
+    c->ring_check_pending = false;
     c->qorder_q0 = c->qorder_q1 = ~0u; // also when this upload fails half way
     std::vector<uint32_t> woff(nseqs), len(nseqs);
     uint64_t nwords = 0, total = 0;
@@ -839,6 +846,138 @@ int dcp_gpu_hit_buffer(dcp_gpu_ctx *c, void **hits_dev, void **nhits_dev, unsign
     return DCP_OK;
 }
 
+// ---- dynamic batching of the query-lane kernels (BASELINE configs[4]) ----------------------------
+// The queries of a scan, sorted by length, are cut into GROUPS of 64 consecutive ones -- what one wavefront sweeps
+// together, one lane each, for as many rows as its longest member has.  A block has `slots` wavefront slots (4: the
+// 256 lanes of a stage; 1 for the three-independent-wavefronts variant) and sits through a tile until its slowest
+// slot is done, so a block of four CONSECUTIVE groups (rounds 1-3) wastes (longest - mean) of its slots' time:
+// a 1 000-query batch of 100 nt .. 10 kbp ran at 0.6 of the rate of a uniform one.  Here each slot holds a LIST of
+// groups, swept one after the other per tile, and the groups are packed into slots so that all slots of all blocks
+// carry about the same number of rows (longest-processing-time-first; the block count is the one that wastes least).
+// Uniform batches come out as before: one group per slot.
+struct QlPlan
+{
+    std::vector<dcp_ql_group> groups;  // in slot order
+    std::vector<uint32_t> slot_first;  // [nqb * slots + 1]
+    std::vector<uint32_t> block_rows;  // [nqb] rows of the block's planes: its longest slot
+    unsigned nqb = 0;
+    unsigned plane_rows = 0;           // max over blocks
+    uint64_t sum_block_rows = 0;       // what a tile costs, summed over the blocks: the cost model's figure
+    unsigned busy_slots = 0;           // slots of the first block that hold a group (cost model)
+};
+// len_sorted: the lengths in ascending order (entry i belongs to qorder[i]).
+static QlPlan plan_query_groups(unsigned const *len_sorted, unsigned nq, unsigned slots)
+{
+    QlPlan pl;
+    unsigned const ng = (nq + 63u) / 64u;
+    struct G
+    {
+        unsigned first, n, lmax, rows;
+    };
+    std::vector<G> gs(ng);
+    uint64_t sum_rows = 0;
+    unsigned max_rows = 0;
+    for (unsigned g = 0; g < ng; ++g)
+    {
+        unsigned const first = g * 64u, n = std::min(64u, nq - first);
+        unsigned const lmax = len_sorted[first + n - 1u];
+        gs[g] = G{first, n, lmax, dcp_qlane_group_rows(lmax)};
+        sum_rows += gs[g].rows;
+        max_rows = std::max(max_rows, gs[g].rows);
+    }
+    // longest first into the least loaded slot; slots sorted by load, `slots` consecutive ones make a block
+    auto pack = [&](unsigned nqb, std::vector<std::vector<unsigned>> &slot_groups, std::vector<uint64_t> &load) {
+        unsigned const S = nqb * slots;
+        slot_groups.assign(S, {});
+        load.assign(S, 0);
+        typedef std::pair<uint64_t, unsigned> LS; // (load, slot): least loaded on top, lowest slot first on ties
+        std::priority_queue<LS, std::vector<LS>, std::greater<LS>> heap;
+        for (unsigned i = 0; i < S; ++i)
+            heap.push(LS(0, i));
+        for (unsigned g = ng; g-- > 0;) // ascending lengths: the last group is the longest
+        {
+            LS top = heap.top();
+            heap.pop();
+            slot_groups[top.second].push_back(g);
+            load[top.second] += gs[g].rows;
+            heap.push(LS(load[top.second], top.second));
+        }
+        std::vector<unsigned> order(S);
+        for (unsigned i = 0; i < S; ++i)
+            order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return load[x] > load[y]; });
+        std::vector<std::vector<unsigned>> sg(S);
+        std::vector<uint64_t> ld(S);
+        for (unsigned i = 0; i < S; ++i)
+            sg[i] = std::move(slot_groups[order[i]]), ld[i] = load[order[i]];
+        slot_groups.swap(sg), load.swap(ld);
+        uint64_t cost = 0;
+        for (unsigned b = 0; b < nqb; ++b)
+            cost += load[(size_t)b * slots]; // the block's longest slot
+        return cost;
+    };
+    // candidate block counts around (all rows) / (slots x the longest group): fewer blocks balance better, more blocks
+    // keep more tasks in flight; take the cheapest, the larger count on ties
+    unsigned const cap = (ng + slots - 1u) / slots; // one group per slot: more blocks than that only adds empty slots
+    uint64_t const denom = (uint64_t)slots * max_rows;
+    unsigned const lo = (unsigned)std::min<uint64_t>(std::max<uint64_t>(sum_rows / denom, 1), cap);
+    unsigned const hi = (unsigned)std::min<uint64_t>(std::max<uint64_t>((sum_rows + denom - 1u) / denom, 1), cap);
+    std::vector<std::vector<unsigned>> best_sg, sg;
+    std::vector<uint64_t> best_ld, ld;
+    uint64_t best_cost = ~0ull;
+    unsigned best_nqb = 0;
+    for (unsigned nqb = lo; nqb <= hi; ++nqb)
+    {
+        uint64_t const cost = pack(nqb, sg, ld);
+        if (cost <= best_cost) best_cost = cost, best_nqb = nqb, best_sg.swap(sg), best_ld.swap(ld);
+    }
+    pl.nqb = best_nqb;
+    pl.sum_block_rows = best_cost;
+    pl.slot_first.assign((size_t)best_nqb * slots + 1u, 0);
+    pl.block_rows.assign(best_nqb, 0);
+    for (unsigned sidx = 0; sidx < best_nqb * slots; ++sidx)
+    {
+        pl.slot_first[sidx] = (uint32_t)pl.groups.size();
+        uint32_t rowbase = 0;
+        for (unsigned g : best_sg[sidx])
+        {
+            pl.groups.push_back(dcp_ql_group{gs[g].first, gs[g].n, rowbase, gs[g].lmax});
+            rowbase += gs[g].rows;
+        }
+        pl.block_rows[sidx / slots] = std::max<uint32_t>(pl.block_rows[sidx / slots], rowbase);
+        if (sidx < slots && rowbase) ++pl.busy_slots;
+    }
+    pl.slot_first.back() = (uint32_t)pl.groups.size();
+    for (unsigned b = 0; b < best_nqb; ++b)
+        pl.plane_rows = std::max(pl.plane_rows, pl.block_rows[b]);
+    return pl;
+}
+
+// The plan as plain arrays (host only; tests/test_query_slots.py checks its invariants on the CPU).
+extern "C" int dcp_plan_query_slots(unsigned const *len_sorted, unsigned nq, unsigned slots_per_block, unsigned *nblocks,
+                                    unsigned long long *sum_block_rows, unsigned *plane_rows, unsigned *groups4,
+                                    unsigned group_cap, unsigned *slot_first, unsigned slot_cap)
+{
+    if (!len_sorted || nq == 0 || (slots_per_block != 1u && slots_per_block != 4u) || !nblocks) return DCP_EINVAL;
+    for (unsigned i = 1; i < nq; ++i)
+        if (len_sorted[i] < len_sorted[i - 1]) return DCP_EINVAL;
+    QlPlan const pl = plan_query_groups(len_sorted, nq, slots_per_block);
+    *nblocks = pl.nqb;
+    if (sum_block_rows) *sum_block_rows = pl.sum_block_rows;
+    if (plane_rows) *plane_rows = pl.plane_rows;
+    if (groups4)
+    {
+        if (group_cap < pl.groups.size()) return DCP_ENOMEM;
+        std::memcpy(groups4, pl.groups.data(), pl.groups.size() * sizeof(dcp_ql_group));
+    }
+    if (slot_first)
+    {
+        if (slot_cap < pl.slot_first.size()) return DCP_ENOMEM;
+        std::memcpy(slot_first, pl.slot_first.data(), pl.slot_first.size() * sizeof(uint32_t));
+    }
+    return DCP_OK;
+}
+
 // Which grid-mode row-sweep kernel scores one size class against `nchunks` queries: rows of the emission table
 // each block stages in LDS and wavefronts per block (dcp_kernels.hip).  Measured on the 20 000-profile DB
 // (profiles/r03/rowsweep_variants.txt, ms per scan for 1 .. 1 000 queries):
@@ -898,7 +1037,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     // One scan is outstanding per context: results (hits, scores, redo lists) are those of the LAST
     // scan.  A scan enqueued while the previous one still has unchecked redo lists first completes
     // that one (its overflow re-run included), so nothing of it is silently half done.
-    if (c->redo_pending)
+    if (c->redo_pending || c->ring_check_pending)
         if (int rc = finish_scan(c)) return rc;
 
     if (int rc = ensure_xtrans(c, prm->multi_hits, prm->hmmer3_compat)) return rc;
@@ -981,19 +1120,20 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             unsigned const NTq = ql_nt;
             std::vector<unsigned> len(c->seq_len.begin() + q_begin, c->seq_len.begin() + q_end);
             std::sort(len.begin(), len.end());
-            double sum_len = 0, sum_block_lmax = 0;
+            double sum_len = 0;
             for (unsigned L : len)
                 sum_len += L;
-            unsigned const nqb = (nq + NTq - 1u) / NTq;
-            for (unsigned b = 0; b < nqb; ++b)
-                sum_block_lmax += len[std::min(nq, (b + 1u) * NTq) - 1u];
+            // rows a tile costs, summed over the blocks of wavefront slots the batch is packed into (plan_query_groups)
+            QlPlan const plan = plan_query_groups(len.data(), nq, NTq / 64u);
+            unsigned const nqb = plan.nqb;
+            double const sum_block_lmax = (double)plan.sum_block_rows;
             unsigned const lmax = len.back();
             double t_rs = (double)c->sum_core * (DCP_NCODES * 4.0) / 3e12 + a.qchunk * lmax * 1.2e-6; // 1.2 us per row
             // (the class rates are those of a 1 000-query step; between 64 and 256 queries the row sweep runs 5 %
             // below them -- 128 queries 450 ms, 160: 558 -- profiles/r03/switch_probe.txt)
             for (int k = 0; k < kNumClasses; ++k)
                 t_rs += 1.05 * (double)c->class_core[k] * sum_len / kClassRate[k];
-            unsigned const waves = std::min(4u, (std::min(nq, NTq) + 63u) / 64u);
+            unsigned const waves = std::max(1u, std::min(4u, plan.busy_slots));
             // (round 3, 20k-profile DB: 96 and 128 queries 477 / 480 ms, 256 queries 659 ms in the single-stage kernel)
             static double const kTrow[4] = {0.52, 0.54, 0.62, 0.73}; // 144..191 queries: 544-555 ms
             double const trow = (w3 ? 0.56 : kTrow[waves - 1u]) * 1e-6; // w3: + one add per gather
@@ -1023,13 +1163,26 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     bool const use_w3 = w3 && !two_stage;
     if (kernel == 2)
     {
-        // queries sorted by length so that the lanes of a block finish together
+        // queries sorted by length, cut into 64-query groups, the groups packed into wavefront slots (plan_query_groups)
         if (c->qorder_q0 != q_begin || c->qorder_q1 != q_end || c->qorder_nt != ql_nt)
         {
-            unsigned const NTq = ql_nt;
-            unsigned const nqb = (nq + NTq - 1u) / NTq;
-            // pinned staging: [nq] order, [nqb + 1] plane offsets
-            size_t const need_stage = (size_t)nq + nqb + 1u;
+            unsigned const NTq = ql_nt, slots = NTq / 64u;
+            std::vector<uint32_t> ord(nq);
+            for (unsigned i = 0; i < nq; ++i)
+                ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+                return c->seq_len[q_begin + x] < c->seq_len[q_begin + y];
+            });
+            std::vector<unsigned> len_sorted(nq);
+            for (unsigned i = 0; i < nq; ++i)
+                len_sorted[i] = c->seq_len[q_begin + ord[i]];
+            QlPlan const plan = plan_query_groups(len_sorted.data(), nq, slots);
+            unsigned const nqb = plan.nqb;
+            if ((uint64_t)plan.plane_rows * NTq * 4u > 0xffffffffull) // 32-bit byte offsets into a block's planes
+                return c->fail(DCP_ENOMEM, "sequences too long for the query-lane kernel (%u plane rows): use kernel = 1", plan.plane_rows);
+            // pinned staging: [nq] order, [nqb + 1] plane offsets, [nslots + 1] slot table, 4 words per group
+            size_t const nslot_words = (size_t)nqb * slots + 1u, ngroup_words = plan.groups.size() * 4u;
+            size_t const need_stage = (size_t)nq + nqb + 1u + nslot_words + ngroup_words;
             if (!c->ev_qstage) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_qstage, hipEventDisableTiming));
             else HIP_TRY(c, hipEventSynchronize(c->ev_qstage)); // the previous layout's copies have left the buffer
             if (c->h_qstage_n < need_stage)
@@ -1039,38 +1192,40 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 HIP_TRY(c, hipHostMalloc((void **)&c->h_qstage, need_stage * sizeof(uint32_t), hipHostMallocDefault));
                 c->h_qstage_n = need_stage;
             }
-            uint32_t *const ord = c->h_qstage, *const wt_off = c->h_qstage + nq;
-            for (unsigned i = 0; i < nq; ++i)
-                ord[i] = i;
-            std::stable_sort(ord, ord + nq, [&](uint32_t x, uint32_t y) {
-                return c->seq_len[q_begin + x] < c->seq_len[q_begin + y];
-            });
-            unsigned lmax = 0;
-            for (unsigned q = q_begin; q < q_end; ++q)
-                lmax = std::max(lmax, c->seq_len[q]);
-            if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
-            HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, ord, nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            // per block of NT queries: the rows of its sequence plane (dcp_qlane_plane_rows of its longest member)
+            uint32_t *const h_ord = c->h_qstage, *const wt_off = h_ord + nq, *const h_slots = wt_off + nqb + 1u,
+                           *const h_groups = h_slots + nslot_words;
+            static_assert(sizeof(dcp_ql_group) == 4 * sizeof(uint32_t), "group records travel as four words");
+            std::memcpy(h_ord, ord.data(), nq * sizeof(uint32_t));
+            std::memcpy(h_slots, plan.slot_first.data(), nslot_words * sizeof(uint32_t));
+            std::memcpy(h_groups, plan.groups.data(), ngroup_words * sizeof(uint32_t));
+            // per block: its window plane, uint16 [block rows + 8][NTq] (the prefetch runs a few rows past the end)
             uint64_t tot = 0;
             wt_off[0] = 0u;
             for (unsigned b = 0; b < nqb; ++b)
             {
-                unsigned const lastq = std::min(nq, (b + 1u) * NTq) - 1u; // ascending lengths
-                tot += (uint64_t)dcp_qlane_plane_rows(c->seq_len[q_begin + ord[lastq]]) * NTq;
+                tot += ((uint64_t)plan.block_rows[b] + 8u) * NTq / 2u;
                 if (tot > 0xffffffffull) return c->fail(DCP_EINVAL, "sequence batch too large");
                 wt_off[b + 1u] = (uint32_t)tot;
             }
+            if (c->d_qorder.n < nq) HIP_TRY(c, c->d_qorder.alloc(nq));
             if (c->d_wt_off.n < nqb + 1u) HIP_TRY(c, c->d_wt_off.alloc(nqb + 1u));
+            if (c->d_slot_first.n < nslot_words) HIP_TRY(c, c->d_slot_first.alloc(nslot_words));
+            if (c->d_ql_groups.n < plan.groups.size()) HIP_TRY(c, c->d_ql_groups.alloc(plan.groups.size()));
             if (c->d_words_t.n < tot) HIP_TRY(c, c->d_words_t.alloc((size_t)tot));
+            HIP_TRY(c, hipMemcpyAsync(c->d_qorder.p, h_ord, nq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipMemcpyAsync(c->d_wt_off.p, wt_off, (nqb + 1u) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_slot_first.p, h_slots, nslot_words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_ql_groups.p, h_groups, ngroup_words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev_qstage, c->stream));
             dcp_qlane_args ta{};
             ta.seq_words = a.seq_words, ta.seq_woff = a.seq_woff, ta.seq_len = a.seq_len;
             ta.qorder = c->d_qorder.p, ta.words_t = c->d_words_t.p, ta.wt_off = c->d_wt_off.p;
+            ta.groups = c->d_ql_groups.p, ta.slot_first = c->d_slot_first.p;
             ta.nseqs = nq, ta.nqblocks = nqb;
             if (dcp_launch_qlane_transpose(&ta, NTq, c->stream)) return c->fail(DCP_EFAIL, "no kernel for %u-query blocks", NTq);
             HIP_TRY(c, hipGetLastError());
-            c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_lmax = lmax, c->qorder_nt = NTq;
+            c->qorder_q0 = q_begin, c->qorder_q1 = q_end, c->qorder_nt = NTq;
+            c->ql_nqb = nqb, c->ql_plane_rows = plan.plane_rows + 8u;
         }
         if (!c->d_task_counter.p) HIP_TRY(c, c->d_task_counter.alloc(1));
     }
@@ -1093,6 +1248,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.qorder = c->d_qorder.p;
         qa.words_t = c->d_words_t.p;
         qa.wt_off = c->d_wt_off.p;
+        qa.groups = c->d_ql_groups.p;
+        qa.slot_first = c->d_slot_first.p;
+        qa.ring_stall = c->ring_stall;
         qa.task_counter = c->d_task_counter.p;
         qa.out_null = a.out_null;
         qa.out_alt = a.out_alt;
@@ -1104,9 +1262,9 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         qa.nprof_total = c->nprof;
         qa.nseqs = nq;
         qa.q_base = q_begin;
-        qa.lmax = c->qorder_lmax;
+        qa.plane_rows = c->ql_plane_rows;
         unsigned const NT = ql_nt;
-        qa.nqblocks = (nq + NT - 1u) / NT;
+        qa.nqblocks = c->ql_nqb;
         uint64_t const ntasks = (uint64_t)c->nprof * qa.nqblocks;
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         qa.ntasks = (unsigned)ntasks;
@@ -1133,20 +1291,18 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 redo_grid[k] = (unsigned)((g + 7) / 8 * 8);
             }
             if (c->d_redo.n < tot) HIP_TRY(c, c->d_redo.alloc((size_t)tot));
-            if (!c->d_redo_n.p) HIP_TRY(c, c->d_redo_n.alloc(DCP_MAX_CLASSES + 1));
-            HIP_TRY(c, hipMemsetAsync(c->d_redo_n.p, 0, (DCP_MAX_CLASSES + 1) * sizeof(unsigned), c->stream));
         }
-        else if (!c->d_redo_n.p)
-        {
-            HIP_TRY(c, c->d_redo_n.alloc(DCP_MAX_CLASSES + 1)); // caps are 0: never written
-            HIP_TRY(c, hipMemsetAsync(c->d_redo_n.p, 0, (DCP_MAX_CLASSES + 1) * sizeof(unsigned), c->stream));
-        }
+        // counters, overflow flag and the ring's error word start every query-lane scan at zero (without redo the
+        // lists' capacities are 0: the counters are never written)
+        if (!c->d_redo_n.p) HIP_TRY(c, c->d_redo_n.alloc(DCP_MAX_CLASSES + 2));
+        HIP_TRY(c, hipMemsetAsync(c->d_redo_n.p, 0, (DCP_MAX_CLASSES + 2) * sizeof(unsigned), c->stream));
         qa.redo = c->d_redo.p;
         qa.redo_n = c->d_redo_n.p;
         qa.redo_overflow = c->d_redo_n.p + DCP_MAX_CLASSES;
-        // scratch = 3 planes x (lmax + 8) rows x NT floats per resident block; long sequences
+        qa.ring_error = c->d_redo_n.p + DCP_MAX_CLASSES + 1;
+        // scratch = 3 planes x plane rows x NT floats per resident block; long sequences
         // (SCHED_SEQ_SIZE allows 1 MiB) get fewer resident blocks so the planes stay within budget
-        uint64_t const per_block = (uint64_t)dcp_qlane_scratch_planes() * ((uint64_t)qa.lmax + 8u) * NT; // floats
+        uint64_t const per_block = (uint64_t)dcp_qlane_scratch_planes() * (uint64_t)qa.plane_rows * NT; // floats
         uint64_t const budget = (uint64_t)64 << 28;                      // 64 GiB of floats / 4
         uint64_t fit = per_block ? budget / per_block : 0;
         // one 512-thread block per CU (two-stage) or two 256-thread blocks (single-stage)
@@ -1154,7 +1310,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         unsigned nblocks = (unsigned)std::min<uint64_t>(std::min<uint64_t>(ntasks, resident_blocks), fit);
         if (use_w3) nblocks = (nblocks + 2u) / 3u * 3u; // whole 3-slot blocks (scratch is sized for every slot)
         if (nblocks == 0)
-            return c->fail(DCP_ENOMEM, "sequence of %u nt is too long for the query-lane kernel: use kernel = 1", qa.lmax);
+            return c->fail(DCP_ENOMEM, "sequences too long for the query-lane kernel (%u plane rows): use kernel = 1", qa.plane_rows);
         size_t const need = (size_t)nblocks * per_block;
         if (c->d_scratch.n < need) HIP_TRY(c, c->d_scratch.alloc(need));
         qa.scratch = c->d_scratch.p;
@@ -1187,6 +1343,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
         c->scanned = true;
         c->redo_pending = redo;
+        c->ring_check_pending = two_stage;
         c->last_redo_pairs = 0;
         c->last_prm = *prm;
         return DCP_OK;
@@ -1298,10 +1455,20 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
 static int finish_scan(dcp_gpu_ctx *c)
 {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (!c->redo_pending) return DCP_OK;
+    if (!c->redo_pending && !c->ring_check_pending) return DCP_OK;
+    bool const redo = c->redo_pending;
     c->redo_pending = false;
-    unsigned n[DCP_MAX_CLASSES + 1];
+    c->ring_check_pending = false;
+    unsigned n[DCP_MAX_CLASSES + 2];
     HIP_TRY(c, hipMemcpy(n, c->d_redo_n.p, sizeof n, hipMemcpyDeviceToHost));
+    // the two-stage kernel's ring hand-shake ran into its poll bound (dcp_qlane.hip, ring_wait): the stages drained,
+    // but rows were computed from values their partner never wrote -- nothing of this scan can be used
+    if (n[DCP_MAX_CLASSES + 1])
+    {
+        c->scanned = false;
+        return c->fail(DCP_EFAIL, "query-lane kernel: the LDS ring hand-shake between the two stages timed out; the scan's results are invalid");
+    }
+    if (!redo) return DCP_OK;
     uint64_t tot = 0;
     for (int k = 0; k < kNumClasses; ++k)
         tot += n[k];
@@ -1324,6 +1491,12 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
     c->rs_force_R = (int)((bw >> 20) & 15u);      // bits 20..23: only the class with this many nodes per lane (0: all)
     c->seg_mode = ((bw >> 24) & 3u) == 1u ? 0 : ((bw >> 24) & 3u) == 2u ? 1 : -1; // bits 24..25: 1 = never the segmented sweep, 2 = always
+    return DCP_OK;
+}
+int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *c, int on)
+{
+    if (!c) return DCP_EINVAL;
+    c->ring_stall = on ? 1u : 0u;
     return DCP_OK;
 }
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)

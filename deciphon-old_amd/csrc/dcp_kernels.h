@@ -119,6 +119,19 @@ struct dcp_ql_prof
     uint32_t needs_exact_e; // a finite MD or DD > 0: E(j) is not the match states' maximum -> row sweep (redo lists)
 };
 
+// A group = up to 64 queries, consecutive in the length order, that ONE wavefront sweeps together (one lane each).
+// A wavefront slot of a block holds a list of groups, swept one after the other per tile: the host packs groups into
+// slots so that the slots of a block finish together whatever the batch's length mix ("dynamic batching": BASELINE
+// configs[4]).  A group's rows are rowbase + 1 .. rowbase + L (L = its longest member) of the slot's column of the
+// block's planes; its region is L + 10 rows (rounded up to even).
+struct dcp_ql_group
+{
+    uint32_t qfirst;  // first entry of qorder[]
+    uint32_t nq;      // queries (lanes in use), 1..64
+    uint32_t rowbase; // first row of the group's region, minus one... row r of the group is plane row rowbase + r
+    uint32_t lmax;    // its longest member
+};
+
 struct dcp_qlane_args
 {
     dcp_ql_prof const *profs; // sorted by ascending size
@@ -131,12 +144,20 @@ struct dcp_qlane_args
     uint32_t const *seq_len;
     float const *xtrans;
     uint32_t const *qorder;   // [nseqs] query indices sorted by length
-    // sequence words of each block of queries, transposed: block qb's word w of lane t sits at
-    // words_t[wt_off[qb] + w * (queries per block) + t] -- one coalesced load per row
+    dcp_ql_group const *groups;  // [ngroups]
+    uint32_t const *slot_first;  // [nqblocks * slots per block + 1]: a slot's groups are groups[slot_first[s] .. slot_first[s + 1])
+    // window plane of each block of query slots: uint16 [plane rows][lanes per block], entry (r, t) = (the window of the
+    // row r of lane t's column) << 4 -- one coalesced load per row; block qb's plane starts at word wt_off[qb]
     uint32_t *words_t;
     uint32_t const *wt_off;   // [nqblocks + 1]
-    float *scratch;           // [nblocks][3 (or 4) planes][lmax + 8][queries per block]
+    float *scratch;           // [nblocks][3 (or 4) planes][plane_rows][lanes per block]
     unsigned *task_counter;
+    // the two-stage kernel's ring hand-shake gives up after a bounded number of polls: it sets *ring_error and both
+    // stages drain (the scan's results are then invalid and dcp_gpu_sync says so).  ring_stall: TEST ONLY (set through
+    // the -DDCP_TEST_HOOKS build's setter, always 0 in the shipped library): stage 0 of the first task's first step
+    // never sweeps, so its partner stage runs into the bound.
+    unsigned *ring_error;
+    unsigned ring_stall;
     // redo lists, one per row-sweep size class: pairs whose B0(j) = N(j) + NB was beaten by the
     // E -> B / J -> B feedback (dcp_qlane.hip header)
     dcp_pair *redo;
@@ -154,9 +175,9 @@ struct dcp_qlane_args
     unsigned nprof_total;
     unsigned nseqs;
     unsigned q_base;
-    unsigned lmax;     // longest resident sequence of this scan
+    unsigned plane_rows; // rows of a block's scratch planes: the longest slot's rows + 8 (prefetch runs past the end)
     unsigned ntasks;   // nprof * nqblocks
-    unsigned nqblocks; // ceil(nseqs / queries per block)
+    unsigned nqblocks; // blocks of query slots
 };
 
 struct dcp_expand_args
@@ -196,7 +217,7 @@ unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);
 unsigned dcp_qlane_scratch_planes(void);
 unsigned dcp_qlane_diag_build(void); // != 0: a -DDCP_QLANE_DIAG timing build (wrong results)
-unsigned dcp_qlane_plane_rows(unsigned lmax); // rows of a query block's sequence plane
+unsigned dcp_qlane_group_rows(unsigned lmax); // plane rows of a group's region (its longest member + 10, even)
 unsigned dcp_qlane_window_planes(void);       // != 0: the plane holds per-row windows (uint16) instead of packed words
 unsigned dcp_qlane_exact_e_by_redo(void);     // != 0: profiles with a positive MD / DD must go through the redo lists
 #ifdef __cplusplus

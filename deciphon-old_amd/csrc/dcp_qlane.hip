@@ -53,7 +53,7 @@ constexpr unsigned kPlanes = kRecomputeB ? 3u : 4u; // scratch planes per block:
 #ifndef DCP_QLANE_DIAG
 #define DCP_QLANE_DIAG 0
 #endif
-constexpr unsigned kWMask = (DCP_QLANE_DIAG & 1) ? 0u : 1023u;
+// (DCP_QLANE_DIAG bit 0 is applied in gather_off)
 
 // Round-3 trims of the row's bookkeeping instructions.  The row is VALU-bound -- 817 SIMD cycles per
 // wavefront-row against 773 for its arithmetic alone (profiles/r03/row_valu.txt) -- so what is left is
@@ -241,6 +241,8 @@ struct LdsLink
     unsigned my_flag;      // byte offset of this stage's flag array (wave-uniform)
     unsigned peer_flag;    // byte offset of the partner wavefront's lane-0 flag (wave-uniform)
     unsigned seen;         // wave-uniform: the partner's progress as last read
+    unsigned dead;         // wave-uniform: a wait of this wavefront ran into kRingSpinBound (ring_wait)
+    unsigned *error;       // the scan's error word (dcp_qlane_args::ring_error)
 };
 // Block LDS of the two-stage kernel: all 160 KiB, laid out so that EVERY access keeps an immediate
 // offset.  Gathers address a tile image as (window bits) + 16-bit immediate: image 0 sits at 0, image 1
@@ -250,7 +252,7 @@ struct LdsLink
 constexpr unsigned kL2TabIN = 43648u;                 // = one tile image: 2 groups x 1364 codes x 16 B
 constexpr unsigned kL2FlagP = kL2TabIN + 2u * 1364u * 4u; // 54 560: producer flags [256]
 constexpr unsigned kL2FlagC = kL2FlagP + kRLanes * 4u;
-constexpr unsigned kL2Null = kL2FlagC + kRLanes * 4u;    // null scores, stage 0 -> final stage
+constexpr unsigned kL2Null = kL2FlagC + kRLanes * 4u;    // (round 2-3: null scores, stage 0 -> final stage; now parked in the planes)
 constexpr unsigned kL2Task = kL2Null + kRLanes * 4u;     // the task word
 constexpr unsigned kL2Tab1 = 65536u;                   // image of the odd tile
 constexpr unsigned kL2Ring = 7u * kRingPlaneBytes;     // 114 688 .. 163 840
@@ -281,17 +283,44 @@ __device__ __forceinline__ void flag_store(lds_uint *flag, unsigned v)
 {
     __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ unsigned ring_wait(LdsLink const &lk, unsigned need)
+// Polls are BOUNDED: the only hang this kernel has ever produced came from this loop (an
+// experimental 8-row ring, round 3), and a hung GPU costs a whole lease.  A legitimate wait is a few rows of the
+// partner's work -- microseconds; kRingSpinBound polls of >= 0.1 us each are a second.  A wavefront that runs into
+// the bound sets the scan's error word and marks its end of the ring dead: from then on it waits for nothing (its
+// rows are garbage, the scan is failed as a whole by dcp_gpu_sync), its partner runs into its own bound at worst
+// once, and the grid drains.
+#ifndef DCP_Q2_BOUND
+#define DCP_Q2_BOUND 1 // 0: the unbounded loop of rounds 2-3 (pricing builds only: profiles/r04/ring_bound_ab.txt)
+#endif
+[[maybe_unused]] constexpr unsigned kRingSpinBound = 1u << 23;
+__device__ __forceinline__ unsigned ring_wait(LdsLink &lk, unsigned need)
 {
     lds_uint *flag = (lds_uint *)(lk.base + lk.peer_flag);
     unsigned v = __builtin_amdgcn_readfirstlane(flag_load(flag));
+#if DCP_Q2_BOUND
+    unsigned spins = 0;
+    while (v < need)
+    {
+        if (lk.dead) break;
+        __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
+        v = __builtin_amdgcn_readfirstlane(flag_load(flag));
+        if (++spins > kRingSpinBound)
+        {
+            lk.dead = 1u;
+            __hip_atomic_store(lk.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    DCP_ISA_MARK("DCP_RING_ACQUIRED"); // acquire: the ring reads that follow stay behind the flag read
+    return lk.dead ? 0x7fffff00u : v; // dead: every later check of this sweep passes
+#else
     while (v < need)
     {
         __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
         v = __builtin_amdgcn_readfirstlane(flag_load(flag));
     }
-    DCP_ISA_MARK("DCP_RING_ACQUIRED"); // acquire: the ring reads that follow stay behind the flag read
+    DCP_ISA_MARK("DCP_RING_ACQUIRED");
     return v;
+#endif
 }
 // boundary values of the row whose scratch-plane byte offset is `rowoff`
 __device__ __forceinline__ float ring_ld(LdsLink const &lk, unsigned rowoff, unsigned plane)
@@ -620,17 +649,16 @@ __device__ __forceinline__ void ql_row(QState<G> &s, TileTrans<G> const &tr, flo
 template <int G, bool FIRST, bool LAST, int NT, int D, int IN = IO_HBM, int OUT = IO_HBM, unsigned TBASE = 0u,
           bool IN16 = kIn16>
 __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 const *tabIN,
-                                         uint32_t const *__restrict__ wordsT,
+                                         uint32_t const *__restrict__ wordsT, unsigned rowbase,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
-                                         SweepOut &o, LdsLink lk
+                                         SweepOut &o, LdsLink &lk
 #if DCP_QLANE_DIAG & 4
                                          , unsigned tile_odd
 #endif
                                          )
 {
     constexpr int KT = 4 * G;
-    constexpr unsigned wmask = kWMask;
 #if DCP_QLANE_DIAG & 4
     // timing build: what a 2-stage tile pipeline would save -- the even -> odd tile boundary goes through
     // ONE plane row (stays in L2, like an LDS ring would keep it on chip), the odd -> even one through HBM
@@ -664,7 +692,9 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     }
     // plane 3 (B0) exists only when the tiles do not recompute N themselves
     float *pXm = sc, *pXd = sc + plane, *pEm = sc + 2 * plane, *pB = sc + (kRecomputeB ? 0 : 3) * plane;
-    unsigned off = tid * 4u; // byte offset of ((j - 1) * NT + tid)
+    // byte offset of ((rowbase + j - 1) * NT + tid): the group's rows are rows rowbase + 1 .. rowbase + L of the slot's
+    // column (rowbase is wave-uniform; the first group of a slot has rowbase 0)
+    unsigned off = (rowbase * (unsigned)NT + tid) * 4u;
 
     // sequence window: w = row j, wn = row j+1 (the word past the last base is padding)
     // Every lane of the wavefront executes every row up to Lwave -- no per-lane
@@ -680,36 +710,30 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // (A load every 16th row inside `if ((pos & 15) == 0)` reaches the next row through a
     // phi copy and costs a vmcnt(0) drain each time.)
     unsigned j = 1;
-    typedef typename std::conditional<kWPlane, uint16_t, unsigned>::type wq_t;
+    static_assert(kWPlane, "the packed-word sequence planes are gone (round 4): a slot's groups are addressed by plane row");
+    typedef uint16_t wq_t;
     wq_t wq[5];
-    unsigned w, wn;
+    unsigned w;
     unsigned lane2 = tid * 2u; // byte offset of this lane in a window-plane row
-    (void)lane2;
-    if constexpr (kWPlane)
+    // this group's rows of the block's window plane [row][lane] of uint16: row r holds (window of row r) << 4
+    // (row 0 unused, the rows past the longest member up to the region's end are there to be prefetched).
+    // wq[r % 5] = row r's window, r = 2..6: a slot is used by exactly one phase (row j reads slot (j + 1) % 5 for its
+    // gather prefetch and then refills it for row j + 6), so no value ever moves between registers.
+    gu16_ptr const wpl = (gu16_ptr)wordsT + (size_t)rowbase * (unsigned)NT;
+    // (lane2 is loop-invariant over a whole task: the optimiser computes it once per kernel and the allocator spills
+    // it; the reload must come HERE, in front of the wait below -- a scratch_load pending on the way into the row
+    // loop is a static vmcnt(0) in the loop body -- so the value is re-defined by an asm the reload has to feed)
+    asm volatile("" : "+v"(lane2));
     {
-        // wordsT = this block's window plane [row][lane] of uint16: row r holds (window of row r) << 4
-        // (row 0 unused, 8 rows past the longest member are there to be prefetched).  wq[r % 5] = row r's
-        // window, r = 2..6: a slot is used by exactly one phase (row j reads slot (j + 1) % 5 for its
-        // gather prefetch and then refills it for row j + 6), so no value ever moves between registers.
-        gu16_ptr const wpl = (gu16_ptr)wordsT;
         w = wpl[NT + tid];
 #pragma unroll
         for (int r = 2; r < 7; ++r)
             wq[r % 5] = wpl[r * NT + tid];
-        wn = 0u;
+        __builtin_amdgcn_sched_barrier(0); // all seven are issued in front of the wait
         // all seven are waited for here, once per sweep: a load still pending on the way into the row loop
         // would make the compiler's (static) wait for its first use drain the loop's own prefetches every
         // fifth row -- the back-edge path has 16+ younger operations behind such a value, the entry path none
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    }
-    else
-    {
-        unsigned const w0 = wordsT[tid];
-#pragma unroll
-        for (int h = 0; h < 5; ++h)
-            wq[h] = w0; // rows 1..5 take bases 2..6: all in word 0
-        w = w0 & 3u & wmask;
-        wn = ((w << 2) | ((w0 >> 2) & 3u)) & wmask;
     }
     RowIn in;
     Ring ring;
@@ -726,14 +750,14 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     {
         // start kRingSkew rows behind the producer, then row 1 -> slot 1
         static_assert(NT == (int)kRLanes, "the ring's row stride is the scratch planes' row stride");
-        unsigned const need0 = Lwave < kRingSkew ? Lwave : kRingSkew;
+        unsigned const need0 = rowbase + (Lwave < kRingSkew ? Lwave : kRingSkew);
         lk.seen = ring_wait(lk, need0);
         DCP_ISA_MARK("DCP_RING_TAKE");
         ring.Xm[1] = ring_ld(lk, off, 0); // row 1
         ring.Xd[1] = ring_ld(lk, off, 1);
         ring.Em[1] = ring_ld(lk, off, 2);
         DCP_ISA_MARK("DCP_RING_TAKEN");
-        ring_publish(lk, off, 1u);
+        ring_publish(lk, off, rowbase + 1u);
         DCP_ISA_MARK("DCP_RING_TAKE_END");
     }
     else
@@ -766,33 +790,19 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
         /* base of row j+2 sits at position j+1 */                                         \
         unsigned const pos = j + 1u;                                                       \
         ql_row<G, FIRST, LAST, PH, NT, D, IN, OUT, TBASE, IN16>(s, tr, tabM, tabIN, go,              \
-                                   kWPlane ? (unsigned)wq[(PH + 1) % 5] : wn, in, ring, pB, pXm,     \
+                                   (unsigned)wq[(PH + 1) % 5], in, ring, pB, pXm,                    \
                                    pXd, pEm, off, xt, active && j <= L, active && j == L,  \
-                                   dirty, o, lk, j, gm QL_DIAG4_ARGS);                     \
-        if constexpr (kWPlane)                                                             \
+                                   dirty, o, lk, rowbase + j, gm QL_DIAG4_ARGS);           \
         {   /* the slot just read (row j+1's window, loaded five rows ago) takes row j+6's: one coalesced */ \
             /* load, SGPR row pointer + the lane's byte offset re-derived from `off`, as below            */ \
             /* wq[] is uint16: the zero-extension then happens where the value is USED (folded into the   */ \
             /* gather masks); as `unsigned` it is a v_and at the loop's back edge, on a value loaded a      */ \
             /* moment ago -- s_waitcnt vmcnt(0) in every fifth row                                          */ \
-            gu16_ptr wrow = (gu16_ptr)wordsT + (pos + 5u) * (unsigned)NT;                     \
+            gu16_ptr wrow = wpl + (pos + 5u) * (unsigned)NT;                                     \
             asm volatile("" : "+s"(wrow));                                                   \
             asm volatile("" : "+v"(lane2)); /* keeps the 32-bit lane offset next to the load */ \
             wq[(PH + 1) % 5] = *(gu16_ptr)((gchar_ptr)wrow + lane2);                          \
         }                                                                                    \
-        else                                                                                 \
-        {                                                                                    \
-        wn = ((wn << 2) | (((unsigned)wq[PH] >> ((pos & 15u) * 2u)) & 3u)) & wmask;                  \
-        {   /* row j + kWD.  The row pointer is wave-uniform: pinning it to SGPRs makes the load     */ \
-            /* "SGPR base + lane offset"; left alone, the compiler hoists wordsT + lane into a 64-bit */ \
-            /* VGPR pair and adds the row offset with a 64-bit VALU add every row                     */ \
-            gu32_ptr wrow = (gu32_ptr)wordsT + ((pos + kWD) >> 4) * (unsigned)NT;                \
-            asm volatile("" : "+s"(wrow));                                                       \
-            /* lane offset re-derived from `off` each row: a loop-invariant one would be widened */ \
-            /* to 64 bits outside the loop and the SGPR-base addressing mode would be lost       */ \
-            wq[(PH + kWD) % 5] = *(gu32_ptr)((gchar_ptr)wrow + (off & ((unsigned)NT * 4u - 1u))); \
-        }                                                                                        \
-        }                                                                                        \
         off += rowstep * 4u;                                                                     \
         QL_DIAG8_WRAP                                                                            \
         QL_DIAG4_STEP                                                                            \
@@ -806,15 +816,16 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
     // A consumer row j prefetches ring row j+1, so a group starting at j needs rows <= j + n written; a
     // producer group writes rows j .. j+n-1, whose slots must have been taken (row - kRD).  A side that
     // has to wait waits for kRingHyst rows more than it needs, so that it polls once per burst.
+    // (flags count PLANE rows, rowbase + j: a slot's groups follow each other in one step without the counters restarting)
     auto ring_sync = [&](unsigned n) {
         if constexpr (!FIRST && IN == IO_LDS)
         {
-            unsigned const need = j + n < Lwave ? j + n : Lwave;
-            if (lk.seen < need) lk.seen = ring_wait(lk, need + kRingHyst < Lwave ? need + kRingHyst : Lwave);
+            unsigned const need = rowbase + (j + n < Lwave ? j + n : Lwave);
+            if (lk.seen < need) lk.seen = ring_wait(lk, need + kRingHyst < rowbase + Lwave ? need + kRingHyst : rowbase + Lwave);
         }
         if constexpr (!LAST && OUT == IO_LDS)
         {
-            unsigned const last = j + n - 1u;
+            unsigned const last = rowbase + j + n - 1u;
             if (last > lk.seen + kRD) lk.seen = ring_wait(lk, last - kRD + kRingHyst);
         }
     };
@@ -843,15 +854,71 @@ __device__ __forceinline__ void fill_tab_in(float *tab, float const *__restrict_
     }
 }
 
-__device__ __forceinline__ unsigned wave_umax(unsigned v)
+// ---- a wavefront slot's groups (dcp_ql_group, dcp_kernels.h) ---------------------------------------------------
+typedef dcp_ql_group const __attribute__((address_space(4))) cgroup;
+typedef uint32_t const __attribute__((address_space(4))) cu32;
+
+// What a lane holds of its group's query while a tile is swept.
+struct GroupLane
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    unsigned q, L, Lwave, rowbase;
+    bool has;
+    LaneXt xt;
+};
+// lane: 0..63 within the wavefront.  Everything about the group is wave-uniform (scalar loads).
+__device__ __forceinline__ void load_group(dcp_qlane_args const &a, unsigned gi, unsigned lane, GroupLane &g)
+{
+    cgroup *gd = (cgroup *)(unsigned long long)(a.groups + gi);
+    unsigned const qfirst = gd->qfirst, nq = gd->nq;
+    g.rowbase = gd->rowbase;
+    g.has = lane < nq;
+    g.q = g.has ? a.qorder[qfirst + lane] : 0u;
+    g.L = g.has ? a.seq_len[g.q] : 0u;
+    g.Lwave = gd->lmax; // = the wavefront's maximum of L: the host sorted by length
+    float const *__restrict__ x = a.xtrans + (size_t)g.q * DCP_XSTRIDE;
+    g.xt.RR = x[DCP_X_RR], g.xt.SB = x[DCP_X_SB], g.xt.SN = x[DCP_X_SN], g.xt.NN = x[DCP_X_NN];
+    g.xt.NB = x[DCP_X_NB], g.xt.ET = x[DCP_X_ET], g.xt.EC = x[DCP_X_EC], g.xt.CC = x[DCP_X_CC];
+    g.xt.CT = x[DCP_X_CT], g.xt.EB = x[DCP_X_EB], g.xt.EJ = x[DCP_X_EJ], g.xt.JJ = x[DCP_X_JJ];
+    g.xt.JB = x[DCP_X_JB];
+    // Everything loaded above is complete -- and known to the compiler's waitcnt pass to be complete -- before a sweep
+    // starts: a load still pending on the way into a row loop (a transition only the epilogue uses, say) makes the
+    // pass put a static s_waitcnt vmcnt(0) into the loop body, which drains the boundary prefetch every fifth row
+    // (profiles/tools/isa_loops.py shows it).
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+}
+// Per-lane values that outlive a sweep (the null score from the first tile's sweep to the last one's; in the
+// two-stage kernel also alt score and feedback flag from the last sweep to the block's epilogue) are parked in a
+// spare row of the group's region of the block's scratch planes: rows rowbase + L + 1 .. + 10 are prefetched from but
+// never written by a sweep.  Byte offset of that row's entry for lane column `col`:
+__device__ __forceinline__ unsigned park_off(GroupLane const &g, unsigned NT, unsigned col)
+{
+    return ((g.rowbase + g.Lwave + 8u) * NT + col) * 4u;
+}
+
+// The pair's results: scores (dense matrices if kept), LRT filter + hit record, or the redo list.
+__device__ __forceinline__ void ql_publish(dcp_qlane_args const &a, dcp_ql_prof const &pm, unsigned q, float nul, float alt,
+                                           bool redo)
+{
+    if (redo)
     {
-        unsigned other = (unsigned)__shfl_xor((int)v, o, 64);
-        v = other > v ? other : v;
+        // B0 was not the solution for this pair (or its profile has a positive MD / DD): the row-sweep kernel scores it
+        unsigned const cls = pm.cls;
+        unsigned const i = atomicAdd(a.redo_n + cls, 1u);
+        if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
+        else *a.redo_overflow = 1u; // host falls back to the row sweep for the whole scan
+        return;
     }
-    return v;
+    size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
+    if (a.out_null) a.out_null[oi] = nul;
+    if (a.out_alt) a.out_alt[oi] = alt;
+    // xmath_lrt_f32 + filter of scan_thread.c:121-123
+    float const lrt = -2 * (nul - alt);
+    if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+    {
+        unsigned const h = atomicAdd(a.nhits, 1u);
+        if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+    }
 }
 
 } // namespace
@@ -866,9 +933,10 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
     float *tabM = lds;
     float2 *tabIN = reinterpret_cast<float2 *>(lds + TAB_FLOATS); // [code] = {insert, background}
     unsigned const tid = threadIdx.x;
-    // +8 rows: the software pipeline reads row j+D's boundary while computing row j
-    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
+    size_t const plane = (size_t)a.plane_rows * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane; // wave-uniform base
+    constexpr unsigned SLOTS = (unsigned)NT / 64u;
+    LdsLink nolink{};
 
     for (;;)
     {
@@ -882,21 +950,12 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
         unsigned const qb = task % a.nqblocks;
         dcp_ql_prof const pm = a.profs[slot];
         unsigned const T = pm.ntiles;
-
-        unsigned const qi = qb * (unsigned)NT + tid;
-        bool const has = qi < a.nseqs;
-        unsigned const q = has ? a.qorder[qi] : 0u;
-        unsigned const L = has ? a.seq_len[q] : 0u;
+        // this wavefront's slot of the block: its groups are swept one after the other, tile by tile
+        unsigned const sidx = __builtin_amdgcn_readfirstlane(qb * SLOTS + (tid >> 6));
+        cu32 *sf = (cu32 *)(unsigned long long)a.slot_first;
+        unsigned const g0 = sf[sidx], g1 = sf[sidx + 1u];
         // wave-uniform (readfirstlane: the compiler cannot see that through the load)
         uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
-        LaneXt xt;
-        {
-            float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
-            xt.RR = x[DCP_X_RR], xt.SB = x[DCP_X_SB], xt.SN = x[DCP_X_SN], xt.NN = x[DCP_X_NN];
-            xt.NB = x[DCP_X_NB], xt.ET = x[DCP_X_ET], xt.EC = x[DCP_X_EC], xt.CC = x[DCP_X_CC];
-            xt.CT = x[DCP_X_CT], xt.EB = x[DCP_X_EB], xt.EJ = x[DCP_X_EJ], xt.JJ = x[DCP_X_JJ];
-            xt.JB = x[DCP_X_JB];
-        }
 
         // the profile's insert and background tables stay in LDS for the whole task
         {
@@ -905,9 +964,9 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
             fill_tab_in<kIn16>(lds + TAB_FLOATS, gi, gn, tid, (unsigned)NT);
         }
 
-        SweepOut o{ninf(), ninf(), ninf()};
-        bool dirty = false;
-        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
+        GroupLane g;
+        bool const single = g1 - g0 == 1u;
+        bool t_loaded = false;
         for (unsigned t = 0; t < T; ++t)
         {
             __syncthreads(); // previous tile's readers are done with tabM
@@ -919,44 +978,36 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
                     dst[i] = src[i];
             }
             __syncthreads();
-            if (Lwave == 0u) continue; // no lane of this wavefront has a query
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
+            for (unsigned gi = g0; gi < g1; ++gi)
+            {
+                // a slot with ONE group (every uniform batch) keeps its lane state in registers over the task's tiles
+                if (!(single && t_loaded)) load_group(a, gi, tid & 63u, g);
+                t_loaded = true;
+                if (g.Lwave == 0u) continue;
+                SweepOut o{ninf(), ninf(), ninf()};
+                bool dirty = false;
 #if DCP_QLANE_DIAG & 4
 #define QL_DIAG4_TILE , (t & 1u)
 #else
 #define QL_DIAG4_TILE
 #endif
 #define QL_SWEEP(F, L_)                                                                          \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{} QL_DIAG4_TILE)
-            if (first && last) QL_SWEEP(true, true);
-            else if (first) QL_SWEEP(true, false);
-            else if (last) QL_SWEEP(false, true);
-            else QL_SWEEP(false, false);
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, nolink QL_DIAG4_TILE)
+                if (first && last) QL_SWEEP(true, true);
+                else if (first) QL_SWEEP(true, false);
+                else if (last) QL_SWEEP(false, true);
+                else QL_SWEEP(false, false);
 #undef QL_SWEEP
-        }
-
-        if (has && (dirty || (kEM && pm.needs_exact_e)))
-        {
-            // B0 was not the solution for this pair (or its profile has a positive MD / DD): the row-sweep kernel scores it
-            unsigned const cls = pm.cls;
-            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
-            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
-            else *a.redo_overflow = 1u; // host falls back to the row sweep for the whole scan
-        }
-        else if (has)
-        {
-            float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
-            float const nul = o.Rn;
-            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
-            if (a.out_null) a.out_null[oi] = nul;
-            if (a.out_alt) a.out_alt[oi] = alt;
-            // xmath_lrt_f32 + filter of scan_thread.c:121-123
-            float const lrt = -2 * (nul - alt);
-            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
-            {
-                unsigned const h = atomicAdd(a.nhits, 1u);
-                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+                // the null score waits for the last tile in the group's spare plane row (written and read by this lane)
+                unsigned const po = park_off(g, (unsigned)NT, tid);
+                if (first && !last) st_off(sc, po, o.Rn);
+                if (last && g.has)
+                {
+                    float const nul = first ? o.Rn : ld_off(sc, po);
+                    ql_publish(a, pm, g.q, nul, fmaxf(o.E + g.xt.ET, o.C + g.xt.CT), dirty || (kEM && pm.needs_exact_e));
+                }
             }
         }
     }
@@ -991,11 +1042,11 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     unsigned const stage = __builtin_amdgcn_readfirstlane(wv >> 2);
     unsigned const tid = threadIdx.x & 255u;
 #endif
-    float *const rnull = lds + kL2Null / 4u;
     unsigned *const s_task_p = reinterpret_cast<unsigned *>(lds + kL2Task / 4u);
     float *const tabM = lds + (stage ? kL2Tab1 / 4u : 0u);
-    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
+    size_t const plane = (size_t)a.plane_rows * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane;
+    constexpr unsigned SLOTS = (unsigned)NT / 64u;
 
 #if DCP_Q2_PRIO == 1
     if (stage == 1u) __builtin_amdgcn_s_setprio(1);
@@ -1007,6 +1058,8 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     lk.my_flag = stage == 0u ? kL2FlagP : kL2FlagC;
     lk.peer_flag = (stage == 0u ? kL2FlagC : kL2FlagP) + (tid & ~63u) * 4u;
     lk.seen = 0u;
+    lk.dead = 0u;
+    lk.error = a.ring_error;
 
     for (;;)
     {
@@ -1019,30 +1072,25 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
         unsigned const qb = task % a.nqblocks;
         dcp_ql_prof const pm = a.profs[slot];
         unsigned const T = pm.ntiles;
-
-        unsigned const qi = qb * (unsigned)NT + tid;
-        bool const has = qi < a.nseqs;
-        unsigned const q = has ? a.qorder[qi] : 0u;
-        unsigned const L = has ? a.seq_len[q] : 0u;
+        // wavefront w of either stage sweeps slot w of the block: the same groups in the same order
+        unsigned const sidx = __builtin_amdgcn_readfirstlane(qb * SLOTS + (tid >> 6));
+        cu32 *sf = (cu32 *)(unsigned long long)a.slot_first;
+        unsigned const g0 = sf[sidx], g1 = sf[sidx + 1u];
         uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
-        LaneXt xt;
-        {
-            float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
-            xt.RR = x[DCP_X_RR], xt.SB = x[DCP_X_SB], xt.SN = x[DCP_X_SN], xt.NN = x[DCP_X_NN];
-            xt.NB = x[DCP_X_NB], xt.ET = x[DCP_X_ET], xt.EC = x[DCP_X_EC], xt.CC = x[DCP_X_CC];
-            xt.CT = x[DCP_X_CT], xt.EB = x[DCP_X_EB], xt.EJ = x[DCP_X_EJ], xt.JJ = x[DCP_X_JJ];
-            xt.JB = x[DCP_X_JB];
-        }
         {
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
             fill_tab_in<false>(lds + kL2TabIN / 4u, gi, gn, threadIdx.x, 512u);
         }
+        // TEST ONLY (dcp_qlane_args::ring_stall, 0 in the shipped library): stage 0 sits out the first step of the
+        // first task, so stage 1 runs into ring_wait's bound -- the path that must end in an error, not in a hang
+        bool const stalled = a.ring_stall != 0u && task == 0u && stage == 0u;
 
-        SweepOut o{ninf(), ninf(), ninf()};
-        bool dirty = false;
-        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
         unsigned const nsteps = (T + 1u) / 2u;
+        unsigned const final_stage = (T - 1u) & 1u; // the stage that sweeps the last tile
+        GroupLane g;
+        bool const single = g1 - g0 == 1u;
+        bool t_loaded = false;
         for (unsigned st = 0; st < nsteps; ++st)
         {
             unsigned const t = 2u * st + stage;
@@ -1058,55 +1106,64 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
             }
             flag_store((lds_uint *)(lk.base + lk.my_flag + tid * 4u), 0u); // row counters restart with every step
             __syncthreads();
-            if (Lwave == 0u || !mine) continue;
+            if (!mine || (stalled && st == 0u)) continue;
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0u, last = t + 1u == T;
 #if DCP_QLANE_DIAG & 4
 #error "the two-stage kernel has no DIAG=4 build"
 #endif
+            for (unsigned gi = g0; gi < g1; ++gi)
+            {
+                // a slot with ONE group (every uniform batch) keeps its lane state in registers over the task's tiles
+                if (!(single && t_loaded)) load_group(a, gi, tid & 63u, g);
+                t_loaded = true;
+                if (g.Lwave == 0u) continue;
+                SweepOut o{ninf(), ninf(), ninf()};
+                bool dirty = false;
     /* tabIN as seen from the gather offsets: its 8-byte rows are reached from (window >> 1), i.e. from half the image base */
 #define QL2_SWEEP(F, L_, IN_, OUT_, TB_)                                                                  \
     ql_sweep<G, F, L_, NT, D, IN_, OUT_, TB_, false>(tt, lds, reinterpret_cast<float2 const *>(lds + (kL2TabIN - TB_ / 2u) / 4u), \
-                                              wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, lk)
-            if (stage == 0u)
-            {
-                if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM, 0u);
-                else if (first) QL2_SWEEP(true, false, IO_HBM, IO_LDS, 0u);
-                else if (last) QL2_SWEEP(false, true, IO_HBM, IO_HBM, 0u);
-                else QL2_SWEEP(false, false, IO_HBM, IO_LDS, 0u);
-                if (first) rnull[tid] = o.Rn;
-            }
-            else
-            {
-                if (last) QL2_SWEEP(false, true, IO_LDS, IO_HBM, kL2Tab1);
-                else QL2_SWEEP(false, false, IO_LDS, IO_HBM, kL2Tab1);
-            }
+                                              wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, lk)
+                if (stage == 0u)
+                {
+                    if (first && last) QL2_SWEEP(true, true, IO_HBM, IO_HBM, 0u);
+                    else if (first) QL2_SWEEP(true, false, IO_HBM, IO_LDS, 0u);
+                    else if (last) QL2_SWEEP(false, true, IO_HBM, IO_HBM, 0u);
+                    else QL2_SWEEP(false, false, IO_HBM, IO_LDS, 0u);
+                }
+                else
+                {
+                    if (last) QL2_SWEEP(false, true, IO_LDS, IO_HBM, kL2Tab1);
+                    else QL2_SWEEP(false, false, IO_LDS, IO_HBM, kL2Tab1);
+                }
 #undef QL2_SWEEP
-        }
-        __syncthreads(); // rnull is visible; nobody is still reading tabIN
-
-        unsigned const final_stage = (T - 1u) & 1u; // the stage that swept the last tile
-        if (stage != final_stage) continue;
-        if (has && (dirty || (kEM && pm.needs_exact_e)))
-        {
-            unsigned const cls = pm.cls;
-            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
-            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
-            else *a.redo_overflow = 1u;
-        }
-        else if (has)
-        {
-            float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
-            float const nul = rnull[tid];
-            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
-            if (a.out_null) a.out_null[oi] = nul;
-            if (a.out_alt) a.out_alt[oi] = alt;
-            float const lrt = -2 * (nul - alt);
-            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
-            {
-                unsigned const h = atomicAdd(a.nhits, 1u);
-                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+                // What outlives the sweep is parked in the group's spare plane row (park_off): the null score by the
+                // stage that swept the first tile, alt score and feedback flag by the one that swept the last; the
+                // epilogue below reads them after the block barrier (the two may be different wavefronts, and with
+                // T = 2 they run in the same step).
+                unsigned const po = park_off(g, (unsigned)NT, tid);
+                if (first) st_off(sc, po, o.Rn);
+                if (last)
+                {
+                    st_off(sc + plane, po, fmaxf(o.E + g.xt.ET, o.C + g.xt.CT));
+                    st_off(sc + 2 * plane, po, dirty ? 1.0f : 0.0f);
+                }
             }
+        }
+        __syncthreads(); // the parked values are visible to the final stage; nobody is still reading tabIN
+
+        if (stage != final_stage) continue;
+        for (unsigned gi = g0; gi < g1; ++gi)
+        {
+            cgroup *gd = (cgroup *)(unsigned long long)(a.groups + gi);
+            GroupLane ge;
+            ge.rowbase = gd->rowbase, ge.Lwave = gd->lmax;
+            if (ge.Lwave == 0u || (tid & 63u) >= gd->nq) continue;
+            unsigned const q = a.qorder[gd->qfirst + (tid & 63u)];
+            unsigned const po = park_off(ge, (unsigned)NT, tid);
+            float const nul = ld_off(sc, po), alt = ld_off(sc + plane, po);
+            bool const dirty = ld_off(sc + 2 * plane, po) != 0.0f;
+            ql_publish(a, pm, q, nul, alt, dirty || (kEM && pm.needs_exact_e));
         }
     }
 }
@@ -1133,8 +1190,9 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
     unsigned const tid = threadIdx.x & 63u;
     float *const tabM = lds + wv * SLICE;
     float2 *const tabIN = reinterpret_cast<float2 *>(tabM + TAB_FLOATS);
-    size_t const plane = ((size_t)a.lmax + 8u) * (unsigned)NT;
+    size_t const plane = (size_t)a.plane_rows * (unsigned)NT;
     float *const sc = a.scratch + ((size_t)blockIdx.x * 3u + wv) * kPlanes * plane;
+    LdsLink nolink{};
 
     for (;;)
     {
@@ -1143,32 +1201,21 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
         unsigned const task = __builtin_amdgcn_readfirstlane(t0); // lane 0's value
         if (task >= a.ntasks) break;
         unsigned const slot = a.nprof - 1u - task / a.nqblocks; // biggest profiles first
-        unsigned const qb = task % a.nqblocks;
+        unsigned const qb = task % a.nqblocks;                  // = the slot: one wavefront slot per 64-lane block
         dcp_ql_prof const pm = a.profs[slot];
         unsigned const T = pm.ntiles;
-
-        unsigned const qi = qb * (unsigned)NT + tid;
-        bool const has = qi < a.nseqs;
-        unsigned const q = has ? a.qorder[qi] : 0u;
-        unsigned const L = has ? a.seq_len[q] : 0u;
+        cu32 *sf = (cu32 *)(unsigned long long)a.slot_first;
+        unsigned const g0 = sf[qb], g1 = sf[qb + 1u];
         uint32_t const *__restrict__ wordsT = a.words_t + __builtin_amdgcn_readfirstlane(a.wt_off[qb]);
-        LaneXt xt;
-        {
-            float const *__restrict__ x = a.xtrans + (size_t)q * DCP_XSTRIDE;
-            xt.RR = x[DCP_X_RR], xt.SB = x[DCP_X_SB], xt.SN = x[DCP_X_SN], xt.NN = x[DCP_X_NN];
-            xt.NB = x[DCP_X_NB], xt.ET = x[DCP_X_ET], xt.EC = x[DCP_X_EC], xt.CC = x[DCP_X_CC];
-            xt.CT = x[DCP_X_CT], xt.EB = x[DCP_X_EB], xt.EJ = x[DCP_X_EJ], xt.JJ = x[DCP_X_JJ];
-            xt.JB = x[DCP_X_JB];
-        }
         {
             float const *__restrict__ gi = a.emis_insert + (size_t)pm.pidx * NC;
             float const *__restrict__ gn = a.emis_null + (size_t)pm.pidx * NC;
             for (unsigned i = tid; i < (unsigned)NC; i += (unsigned)NT)
                 tabIN[i] = float2{gi[i], gn[i]};
         }
-        SweepOut o{ninf(), ninf(), ninf()};
-        bool dirty = false;
-        unsigned const Lwave = __builtin_amdgcn_readfirstlane(wave_umax(L));
+        GroupLane g;
+        bool const single = g1 - g0 == 1u;
+        bool t_loaded = false;
         for (unsigned t = 0; t < T; ++t)
         {
             {
@@ -1179,77 +1226,74 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
                     dst[i] = src[i];
             }
             compiler_fence(); // the sweep's gathers stay behind the image's stores (same wavefront: LDS keeps the order)
-            if (Lwave == 0u) continue;
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
-#define QLW_SWEEP(F, L_)                                                                                  \
-    ql_sweep<G, F, L_, NT, D, IO_HBM, IO_HBM, 0u, false>(tt, tabM, tabIN, wordsT, L, Lwave, has, sc, plane, tid, xt, dirty, o, LdsLink{})
-            if (first && last) QLW_SWEEP(true, true);
-            else if (first) QLW_SWEEP(true, false);
-            else if (last) QLW_SWEEP(false, true);
-            else QLW_SWEEP(false, false);
-#undef QLW_SWEEP
-            compiler_fence(); // ... and the next image's stores behind this sweep's gathers
-        }
-        if (has && (dirty || (kEM && pm.needs_exact_e)))
-        {
-            unsigned const cls = pm.cls;
-            unsigned const i = atomicAdd(a.redo_n + cls, 1u);
-            if (i < a.redo_cap[cls]) a.redo[a.redo_base[cls] + i] = dcp_pair{q, pm.rs_slot};
-            else *a.redo_overflow = 1u;
-        }
-        else if (has)
-        {
-            float const alt = fmaxf(o.E + xt.ET, o.C + xt.CT);
-            float const nul = o.Rn;
-            size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
-            if (a.out_null) a.out_null[oi] = nul;
-            if (a.out_alt) a.out_alt[oi] = alt;
-            float const lrt = -2 * (nul - alt);
-            if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+            for (unsigned gi = g0; gi < g1; ++gi)
             {
-                unsigned const h = atomicAdd(a.nhits, 1u);
-                if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pm.pidx, nul, alt};
+                // a slot with ONE group (every uniform batch) keeps its lane state in registers over the task's tiles
+                if (!(single && t_loaded)) load_group(a, gi, tid, g);
+                t_loaded = true;
+                if (g.Lwave == 0u) continue;
+                SweepOut o{ninf(), ninf(), ninf()};
+                bool dirty = false;
+#define QLW_SWEEP(F, L_)                                                                                  \
+    ql_sweep<G, F, L_, NT, D, IO_HBM, IO_HBM, 0u, false>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, nolink)
+                if (first && last) QLW_SWEEP(true, true);
+                else if (first) QLW_SWEEP(true, false);
+                else if (last) QLW_SWEEP(false, true);
+                else QLW_SWEEP(false, false);
+#undef QLW_SWEEP
+                unsigned const po = park_off(g, (unsigned)NT, tid);
+                if (first && !last) st_off(sc, po, o.Rn);
+                if (last && g.has)
+                {
+                    float const nul = first ? o.Rn : ld_off(sc, po);
+                    ql_publish(a, pm, g.q, nul, fmaxf(o.E + g.xt.ET, o.C + g.xt.CT), dirty || (kEM && pm.needs_exact_e));
+                }
             }
+            compiler_fence(); // ... and the next image's stores behind this sweep's gathers
         }
     }
 }
 
-// kWPlane: the block's plane is uint16 [rows][NT] starting at word wt_off[qb] of words_t: entry (r, t) = (window of
-// row r of the query in lane t) << 4, the window being the base-4 value of the last five bases up to position
-// r (zeros before the start, anything valid past the end).  Otherwise: word w of the query (0 past its end).
+// The block's window plane: uint16 [rows][NT] starting at word wt_off[qb] of words_t.  Lane t of wavefront slot s
+// holds, for every group of the slot, rows rowbase + 0 .. rowbase + lmax + 9 of column t: entry (rowbase + r, t) =
+// (window of row r of the group's query in lane t) << 4, the window being the base-4 value of the last five bases up
+// to position r (zeros before the start and past the end).  Rows no group owns are zeroed: every entry is a valid
+// gather offset whatever a prefetch reads.
 template <int NT>
 __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
 {
     unsigned const qb = blockIdx.x, tid = threadIdx.x;
-    unsigned const qi = qb * (unsigned)NT + tid;
-    bool const has = qi < a.nseqs;
-    unsigned const q = has ? a.qorder[qi] : 0u;
-    uint32_t const *__restrict__ src = a.seq_words + a.seq_woff[q];
-    // rows of the block's plane: uint16 entries (two per word) with window planes, else one word per entry
-    unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) * (kWPlane ? 2u : 1u) / (unsigned)NT;
-    uint32_t *dst = a.words_t + a.wt_off[qb];
-    if constexpr (kWPlane)
+    unsigned const rows = (a.wt_off[qb + 1] - a.wt_off[qb]) * 2u / (unsigned)NT;
+    uint16_t *dst = reinterpret_cast<uint16_t *>(a.words_t + a.wt_off[qb]);
+    unsigned const sidx = qb * ((unsigned)NT / 64u) + (tid >> 6);
+    unsigned const g0 = a.slot_first[sidx], g1 = a.slot_first[sidx + 1u];
+    unsigned r = 0; // next plane row of this lane's column to write
+    for (unsigned gi = g0; gi < g1; ++gi)
     {
+        dcp_ql_group const g = a.groups[gi];
+        bool const has = (tid & 63u) < g.nq;
+        unsigned const q = has ? a.qorder[g.qfirst + (tid & 63u)] : 0u;
+        uint32_t const *__restrict__ src = a.seq_words + a.seq_woff[q];
         unsigned const len = has ? a.seq_len[q] : 0u;
+        for (; r < g.rowbase; ++r)
+            dst[r * (unsigned)NT + tid] = 0;
         unsigned w = 0, word = 0;
-        for (unsigned r = 0; r < rows; ++r)
+        unsigned const gr = g.lmax + 10u;
+        for (unsigned k = 0; k < gr && r < rows; ++k, ++r)
         {
-            if (r >= 1u)
+            if (k >= 1u)
             {
-                unsigned const pos = r - 1u; // row r ends with base r - 1
+                unsigned const pos = k - 1u; // row k ends with base k - 1
                 if ((pos & 15u) == 0u) word = pos < len ? src[pos >> 4] : 0u;
                 w = ((w << 2) | ((pos < len ? word >> ((pos & 15u) * 2u) : 0u) & 3u)) & 1023u;
             }
-            reinterpret_cast<uint16_t *>(dst)[r * (unsigned)NT + tid] = (uint16_t)(w << 4);
+            dst[r * (unsigned)NT + tid] = (uint16_t)(w << 4);
         }
     }
-    else
-    {
-        unsigned const nw = has ? a.seq_len[q] / 16u + 3u : 0u; // words the upload packed for q
-        for (unsigned w = 0; w < rows; ++w)
-            dst[w * (unsigned)NT + tid] = w < nw ? src[w] : 0u;
-    }
+    for (; r < rows; ++r)
+        dst[r * (unsigned)NT + tid] = 0;
 }
 
 template <int G, int NT, int D>
@@ -1272,10 +1316,9 @@ extern "C" unsigned dcp_qlane_block_size(void) { return DCP_QLANE_NT; }
 extern "C" unsigned dcp_qlane_tile_nodes(void) { return 8u; }
 extern "C" unsigned dcp_qlane_scratch_planes(void) { return kPlanes; }
 extern "C" unsigned dcp_qlane_diag_build(void) { return DCP_QLANE_DIAG; }
-// rows of a block's sequence plane for a longest member of `lmax` bases: window rows 0..lmax + 8, or packed words
-// 32-bit words per lane of a block's sequence plane for a longest member of `lmax` bases: uint16 window rows
-// 0..lmax + 8 (an even number of rows), or packed words
-extern "C" unsigned dcp_qlane_plane_rows(unsigned lmax) { return kWPlane ? (lmax + 10u) / 2u : lmax / 16u + 3u; }
+// plane rows of a group's region for a longest member of `lmax` bases: rows 0 .. lmax + 9, an even number (the window
+// plane holds two uint16 rows per 32-bit word and lane)
+extern "C" unsigned dcp_qlane_group_rows(unsigned lmax) { return (lmax + 11u) & ~1u; }
 extern "C" unsigned dcp_qlane_window_planes(void) { return kWPlane ? 1u : 0u; }
 extern "C" unsigned dcp_qlane_exact_e_by_redo(void) { return kEM ? 1u : 0u; }
 

@@ -725,7 +725,8 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     {
         /* prefetch up to `batch` sequences; each is copied, the source may reuse its buffer (scan.c:227-229) */
         unsigned nb = 0;
-        while (nb < batch)
+        unsigned long symbols = 0; /* of this pass: it also closes at cfg.batch_symbols (a pass is sized by work) */
+        while (nb < batch && (cfg.batch_symbols == 0 || nb == 0 || symbols < cfg.batch_symbols))
         {
             struct scan_seq s = {0, NULL};
             enum rc r = next_seq(arg, &s);
@@ -748,6 +749,7 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
             }
             bseq[cur][nb] = imm_seq(imm_str(btext[cur][nb]), abc);
             bid[cur][nb] = s.id;
+            symbols += (unsigned long)strlen(btext[cur][nb]);
             ++nb;
         }
         if (rc || nb == 0) break;
@@ -860,7 +862,7 @@ enum rc scan_run_local(char const *db_filename, struct scan_seq const *seqs, uns
 {
     if (!seqs || !prods || batch == 0) return fail(RC_EINVAL, "bad scan arguments");
     struct list_source src = {seqs, nseqs, 0};
-    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true, false, NULL, NULL};
+    struct scan_cfg cfg = {scan_id, multi_hits, hmmer3_compat, lrt_threshold, batch, true, false, NULL, NULL, 0};
     enum rc rc = scan_run_source(db_filename, cfg, nthreads, list_next, &src);
     if (rc) return rc;
     char buf[1 << 16];

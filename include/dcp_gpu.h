@@ -303,6 +303,10 @@ int dcp_gpu_hit_buffer(dcp_gpu_ctx *, void **hits_dev, void **nhits_dev, unsigne
  * (default 2^26 pairs; 0 restores it) so a test can reach the overflow path.  Results are unaffected:
  * an overflowed scan is repeated with the row-sweep kernel. */
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *, unsigned cap);
+/* Same build only.  on != 0: in the next two-stage query-lane scans, stage 0 of the first task sits out its first
+ * step, so its partner stage runs into the bound of the LDS ring's hand-shake: the kernel must drain and
+ * dcp_gpu_sync must return DCP_EFAIL (never a hang). */
+int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *, int on);
 /* Same build only.  Forces the grid-mode row-sweep kernel variant -- leading emission rows a block stages in
  * LDS (0, 20 or 84) and, in `block_waves`: bits 0..7 wavefronts per block (0: the default), bits 8..15 KiB of
  * unused LDS per block (an occupancy experiment), bit 16 the two-rows-ahead prefetch variant, bits 20..23 the
@@ -469,6 +473,19 @@ void dcp_dist_free_hits(struct dcp_hit *hits);
  * (seq_idx, profile_idx).  Returns the total, -1 if cap is too small. */
 long dcp_dist_merge_hits(unsigned const *counts, unsigned const *profile_offset, int nranks,
                          struct dcp_hit const *records, struct dcp_hit *out, unsigned cap);
+
+/* Dynamic batching of the query-lane kernels, host side only (what dcp_gpu_scan does with a batch whose automatic
+ * or forced kernel is a query-lane one): the queries in ascending length order are cut into groups of 64 -- one
+ * wavefront's lanes -- and the groups are packed into wavefront slots (4 per 256-lane block, 1 for the
+ * 64-lane variant) so that the slots of every block carry about the same number of DP rows; a slot sweeps its
+ * groups one after the other.  len_sorted: ascending lengths.  Out: the block count, the rows a tile costs summed
+ * over the blocks (each block's longest slot: the kernel-choice model's figure), the longest slot's rows; optionally
+ * the groups as 4 words each {first query (index into the sorted order), queries, first plane row, longest member}
+ * in slot order and slot_first[nblocks * slots + 1].  DCP_EINVAL for unsorted input, DCP_ENOMEM if a capacity
+ * (group_cap in groups, slot_cap in words) is too small. */
+int dcp_plan_query_slots(unsigned const *len_sorted, unsigned nq, unsigned slots_per_block, unsigned *nblocks,
+                         unsigned long long *sum_block_rows, unsigned *plane_rows, unsigned *groups4,
+                         unsigned group_cap, unsigned *slot_first, unsigned slot_cap);
 
 /* Work accounting of the last scan (or of a full scan if none ran yet):
  * alt-model DP cells = sum over pairs of core_size * L (the Gcell/s numerator)

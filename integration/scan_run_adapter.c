@@ -19,7 +19,7 @@
  * This file is the SEAM only.  It is compiled inside the reference tree in place of src/server/scan.c
  * (INTEGRATION.md): the scheduler client (src/sched/api.c), its structs (the third-party
  * deciphon-sched "sched/structs.h"), job.c and file.c stay the reference's.  What differs from the
- * reference loop is inside scan_run_source: `SCAN_RUN_BATCH` sequences are fetched per device pass
+ * reference loop is inside scan_run_source: `SCAN_RUN_BATCH_SYMBOLS` bases (at most `SCAN_RUN_BATCH` sequences) are fetched per device pass
  * instead of one, partitions are device contexts (one host thread per GPU), and progress is consumed per
  * pass instead of per pair.  tests/c/test_scan_run_adapter.c compiles this file unchanged against stub
  * declarations of those interfaces and checks its products against scan_run_local's, row for row.
@@ -32,8 +32,15 @@
 
 #include <string.h>
 
+/* A device pass is sized by work (BASELINE configs[4] "dynamic batching"): it closes at
+ * SCAN_RUN_BATCH_SYMBOLS bases -- about 2 000 sequences of 1 kbp, or 1 000 of a 100 nt .. 10 kbp mix, some five seconds
+ * of device time against a Pfam-sized partition -- or at SCAN_RUN_BATCH sequences (what the host buffers are sized for),
+ * whichever comes first.  Inside a pass the device packs the sequences by length into its wavefront slots. */
 #ifndef SCAN_RUN_BATCH
-#define SCAN_RUN_BATCH 1024 /* sequences prefetched per device pass */
+#define SCAN_RUN_BATCH 16384
+#endif
+#ifndef SCAN_RUN_BATCH_SYMBOLS
+#define SCAN_RUN_BATCH_SYMBOLS (2ul << 20)
 #endif
 
 /* one scan at a time per process, like the reference's file-scope `scan`, `api_rc`, `db` (scan.c:41-43) */
@@ -148,7 +155,7 @@ enum rc scan_run(int64_t job_id, unsigned num_threads)
     }
     ad.total = (unsigned long)nseqs * count_profiles(ad.db.filename);
 
-    /* the loop of scan.c:224-258, `SCAN_RUN_BATCH` sequences per pass; lrt threshold 10 as scan.c:221 */
+    /* the loop of scan.c:224-258, a pass of `SCAN_RUN_BATCH_SYMBOLS` bases (at most `SCAN_RUN_BATCH` sequences); lrt threshold 10 as scan.c:221 */
     sched_seq_init(&ad.seq);
     ad.last_seq_id = ad.seq.id;
     struct scan_cfg cfg = {.scan_id = ad.sched.id,
@@ -159,7 +166,8 @@ enum rc scan_run(int64_t job_id, unsigned num_threads)
                            .balance_by_cells = true, /* partitions = GPUs: balance by work, not by count */
                            .keep_resident = true,    /* the next job on the same database starts at the sequences */
                            .progress = on_progress,
-                           .progress_arg = NULL};
+                           .progress_arg = NULL,
+                           .batch_symbols = SCAN_RUN_BATCH_SYMBOLS};
     rc = scan_run_source(ad.db.filename, cfg, num_threads, next_seq, NULL);
     if (rc)
     {

@@ -440,6 +440,67 @@ static void resident_reuse(void)
     free(fresh), free(first), free(again), free(other), free(third);
 }
 
+/* cfg.batch_symbols: a device pass closes at a number of SYMBOLS as well as at a number of sequences (a pass is
+ * sized by its work).  Products do not depend on where the passes are cut; the progress callback is called once per
+ * pass and partition, so it counts the passes. */
+static unsigned long g_passes, g_pairs;
+static void count_pass(unsigned long pairs, void *arg)
+{
+    (void)arg;
+#pragma omp critical(count_pass)
+    {
+        ++g_passes;
+        g_pairs += pairs;
+    }
+}
+static char *run_sized(struct scan_seq const *seqs, unsigned n, unsigned batch, unsigned long symbols)
+{
+    struct list_src src = {seqs, n, 0};
+    struct scan_cfg cfg = {.scan_id = 9, .multi_hits = true, .hmmer3_compat = false, .lrt_threshold = 10.0, .batch = batch,
+                           .balance_by_cells = true, .keep_resident = false, .progress = count_pass, .batch_symbols = symbols};
+    g_passes = g_pairs = 0;
+    CHECK(scan_run_source(g_db_path, cfg, 1, list_src_next, &src) == RC_OK);
+    char *text = slurp(prod_final_fp());
+    prod_final_cleanup();
+    return text;
+}
+static void passes_sized_by_symbols(void)
+{
+    enum { NSEQ = 9 };
+    static char text[NSEQ][700];
+    struct scan_seq seqs[NSEQ];
+    unsigned long len[NSEQ], total = 0;
+    for (unsigned q = 0; q < NSEQ; ++q)
+    {
+        /* lengths from 4 to a few hundred symbols, two of them with a domain */
+        char const *dom = q == 2 ? g_domain[1] : q == 7 ? g_domain[3] : "";
+        size_t at = 0;
+        for (unsigned r = 0; r < 1u + 7u * (q % 4u); ++r)
+            at += (size_t)snprintf(text[q] + at, sizeof text[q] - at, "ACGT");
+        snprintf(text[q] + at, sizeof text[q] - at, "%s%s", dom, q & 1 ? "GATTACA" : "");
+        seqs[q] = (struct scan_seq){3000 + q, text[q]};
+        total += len[q] = strlen(text[q]);
+    }
+    char *by_count = run_sized(seqs, NSEQ, 100, 0); /* one pass of nine sequences */
+    unsigned long const pairs = g_pairs;
+    CHECK(g_passes == 1 && pairs > 0);
+    char *by_work = run_sized(seqs, NSEQ, 100, 60); /* a pass closes once it holds >= 60 symbols */
+    unsigned long want = 0, acc = 0;
+    for (unsigned q = 0; q < NSEQ; ++q)
+    {
+        acc += len[q];
+        if (acc >= 60 || q + 1 == NSEQ) ++want, acc = 0;
+    }
+    CHECK(want >= 3 && g_passes == want && g_pairs == pairs);
+    CHECK(strcmp(by_count, by_work) == 0); /* same rows, same order */
+    char *one_each = run_sized(seqs, NSEQ, 100, 1); /* every pass holds at least one sequence */
+    CHECK(g_passes == NSEQ && g_pairs == pairs && strcmp(by_count, one_each) == 0);
+    char *count_first = run_sized(seqs, NSEQ, 2, total); /* the count bound closes the pass first */
+    CHECK(g_passes == (NSEQ + 1) / 2 && strcmp(by_count, count_first) == 0);
+    CHECK(strstr(by_count, "9\t3002\t") != NULL && strstr(by_count, "9\t3007\t") != NULL);
+    free(by_count), free(by_work), free(one_each), free(count_first);
+}
+
 static void scan_run_batched(void)
 {
     enum { NSEQ = 7 };
@@ -661,6 +722,7 @@ int main(void)
     press_db();
     scan_threads();
     scan_run_batched();
+    passes_sized_by_symbols();
     resident_reuse();
     remove(g_db_path);
     one_process_per_gpu();

@@ -864,6 +864,97 @@ def test_full_size_c3_step_both_kernels_agree(dcp, oracle32, c3_profiles, bench_
         sc.close()
 
 
+def test_packed_slots_skewed_lengths_bit_exact(dcp, oracle32, scanner):
+    """Dynamic batching (plan_query_groups, dcp_gpu.hip): with skewed lengths a wavefront slot of a query-lane block
+    sweeps SEVERAL 64-query groups one after the other per tile -- plane rows offset by the groups before it, the
+    two-stage kernel's ring counting plane rows across groups, null / alt scores parked in the planes' spare rows
+    between the first and the last tile.  700 queries of 1 .. 3 000 nt (11 groups in one block of four slots: one slot
+    holds the longest group, the others two to five), profiles of 1, 2, 3 and 12 tiles (odd and even tile counts: either
+    stage sweeps the last tile), planted hits in a short and in a long group: every score and the hit list equal the
+    oracle's float32 recursion on the product's tables bit for bit, on both query-lane kernels; multi- and uni-hit."""
+    import ctypes as C
+    rng = np.random.default_rng(4242)
+    sizes = (5, 13, 23, 92)
+    params = [pfam_like_params(rng, M) for M in sizes]
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    for p in profiles:
+        prof_eps[id(p)] = cfg.epsilon
+    lens = np.round(np.exp(rng.uniform(np.log(1.0), np.log(3000.0), 700))).astype(int)
+    seqs = [rng.integers(0, 4, int(n), dtype=np.uint8) for n in lens]
+    order = np.argsort(lens, kind="stable")
+    short_q, long_q = int(order[100]), int(order[690])
+    seqs[short_q] = planted_query(rng, oracle32.new(*params[1], ENTRY_DIST_OCCUPANCY, 0.01), sizes[1], flank=3)
+    seqs[long_q] = np.concatenate([rng.integers(0, 4, 1500, dtype=np.uint8),
+                                   planted_query(rng, oracle32.new(*params[3], ENTRY_DIST_OCCUPANCY, 0.01), sizes[3], flank=700)])
+    # the plan this batch gets: one block, some slot with several groups
+    ls = np.sort(np.array([len(s) for s in seqs], np.uint32))
+    nb, cost = C.c_uint(0), C.c_ulonglong(0)
+    f = dcp.lib.dcp_plan_query_slots
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong), C.c_void_p, C.c_void_p,
+                  C.c_uint, C.c_void_p, C.c_uint]
+    sf = np.zeros(64, np.uint32)
+    assert f(ls.ctypes.data, len(ls), 4, C.byref(nb), C.byref(cost), None, None, 0, sf.ctypes.data, 64) == 0
+    assert nb.value == 1 and np.diff(sf[:5].astype(int)).max() >= 3 and np.diff(sf[:5].astype(int)).min() >= 1
+    scanner.upload_db(profiles, expand_on_host=True)
+    scanner.upload_seqs(seqs)
+    for multi in (True, False):
+        on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
+        lrt = np.float32(-2) * (on - oa)  # xmath_lrt_f32, scan_thread.c:121-123
+        want_hits = {(int(q), int(p)) for q, p in zip(*np.nonzero(np.isfinite(lrt) & ~(lrt < np.float32(10.0))))}
+        for k in (dcp.KERNEL_QLANE, dcp.KERNEL_QLANE2):
+            scanner.scan(multi, False, 10.0, kernel=k)
+            gn, ga = scanner.scores()
+            assert same_bits(gn, on) and same_bits(ga, oa), (multi, k)
+            got = {(int(h["seq_idx"]), int(h["profile_idx"])) for h in scanner.hits()}
+            assert got == want_hits and {(short_q, 1), (long_q, 3)} <= got
+        # a ranged scan re-plans for its own queries
+        scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_QLANE2, q_range=(130, 570))
+        gn2, ga2 = scanner.scores()
+        assert same_bits(gn2[130:570], on[130:570]) and same_bits(ga2[130:570], oa[130:570])
+
+
+def test_ring_hand_shake_is_bounded(dcp, hooks_scanner):
+    """the two-stage kernel's LDS ring hand-shake polls a bounded number of times.  Through the
+    tests' own -DDCP_TEST_HOOKS build one stage of the first task is made to sit out a step: its partner must run into
+    the bound, set the scan's error word and drain -- dcp_gpu_sync returns RC_EFAIL (no hang, no scores taken for
+    good) -- and the next scan on the same context is correct again."""
+    import time
+    sc = hooks_scanner
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.sample(77 + i, m, cfg) for i, m in enumerate((40, 17, 9, 64))]
+    rng = np.random.default_rng(3)
+    seqs = rand_seqs(rng, 300, 50, 400)
+    sc.upload_db(profiles)
+    sc.upload_seqs(seqs)
+    sc.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+    want_n, want_a = sc.scores()
+    sc.test_set_ring_stall(True)
+    try:
+        t0 = time.time()
+        with pytest.raises(dcp.DcpError) as ei:
+            sc.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE2)  # sync=True: dcp_gpu_sync reports it
+        took = time.time() - t0
+        assert ei.value.rc == dcp.RC_EFAIL and "hand-shake" in str(ei.value)
+        assert took < 60.0, took  # bounded: a few seconds of polling, not the lease
+        with pytest.raises(dcp.DcpError):
+            sc.scores()  # nothing of the failed scan is handed out
+    finally:
+        sc.test_set_ring_stall(False)
+    sc.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE2)
+    gn, ga = sc.scores()
+    assert same_bits(gn, want_n) and same_bits(ga, want_a)
+    # a uni-hit scan (no redo lists to check) reports the error word too
+    sc.test_set_ring_stall(True)
+    try:
+        with pytest.raises(dcp.DcpError) as ei:
+            sc.scan(False, False, 10.0, kernel=dcp.KERNEL_QLANE2)
+        assert ei.value.rc == dcp.RC_EFAIL
+    finally:
+        sc.test_set_ring_stall(False)
+
+
 def test_mixed_length_stress_both_kernels_agree(dcp):
     """BASELINE.json configs[4] shape at a size both kernels finish in seconds: 2 000 profiles with
     M log-uniform on 50..2000 x 600 queries log-uniform on 100..10 000 nt (length-sorted blocks, a partial
