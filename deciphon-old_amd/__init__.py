@@ -180,6 +180,7 @@ def _load(path=None, hooks=False):
         sig["dcp_gpu_test_set_redo_cap"] = (I, [P, U])
         sig["dcp_gpu_test_set_rowsweep_variant"] = (I, [P, I, U])
         sig["dcp_gpu_test_set_ring_stall"] = (I, [P, I])
+        sig["dcp_gpu_test_set_seg_col_bytes"] = (I, [P, C.c_ulonglong])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -568,6 +569,10 @@ class Scanner:
         """TEST-ONLY (test-hooks build): the next two-stage query-lane scans stall one stage of the first task, so its
         partner runs into the ring hand-shake's poll bound (the scan must fail with RC_EFAIL, not hang)."""
         self._check(self._lib.dcp_gpu_test_set_ring_stall(self._c, int(bool(on))))
+
+    def test_set_seg_col_bytes(self, nbytes):
+        """TEST-ONLY (test-hooks build): cap on a size class's boundary columns in the segmented row sweep (0: default)."""
+        self._check(self._lib.dcp_gpu_test_set_seg_col_bytes(self._c, int(nbytes)))
 
     def test_set_rowsweep_variant(self, stage_rows, block_waves=0):
         """TEST-ONLY (test-hooks build): force the grid-mode row-sweep kernel variant; stage_rows < 0: automatic."""

@@ -177,6 +177,7 @@ struct dcp_gpu_ctx
     DevBuf<dcp_pair> d_seg_redo;
     DevBuf<unsigned> d_seg_redo_n; // [DCP_MAX_CLASSES]
     int seg_mode = -1;             // test hook: 0 never, 1 always where a kernel exists, -1 automatic
+    uint64_t seg_col_bytes = (uint64_t)6 << 30; // cap on one class's boundary columns (test hook: shrink it to reach the chunked path)
     unsigned n_launched = 0;
 
     int fail(int rc, char const *fmt, ...)
@@ -1356,15 +1357,17 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     // fork / join around the class launches when no single one fills the chip
     bool const overlap = (uint64_t)nq * c->nprof < ((uint64_t)1 << 21);
     c->last_overlapped = overlap;
-    // Multi-wavefront classes with a segmented-sweep kernel (dcp_kernels.hip): one wavefront per pair over the
-    // profile's segments with B(j) = N(j) + NB, the pairs with feedback finished by the exact kernel behind it.
-    // Per class: scratch columns for the persistent grid's wavefronts and a redo list of all its pairs.
+    // Multi-wavefront classes with a segmented-sweep kernel (dcp_kernels.hip): one wavefront per pair, one SEGMENT of
+    // the profile per launch, B(j) = N(j) + NB, the pairs with feedback finished by the exact kernel behind it.
+    // Per class: two boundary columns of lmax + 2 rows of 16 bytes per pair, and a redo list of all its pairs.  The
+    // columns of a class are capped at kSegColBytes: beyond, its queries are swept chunk by chunk.
     unsigned lmax_scan = 0;
     for (unsigned q = q_begin; q < q_end; ++q)
         lmax_scan = std::max(lmax_scan, c->seq_len[q]);
-    unsigned const seg_stride = 2u * (lmax_scan + 2u); // float4 per wavefront: two columns of lmax + 2 rows
-    unsigned seg_blocks[kNumClasses] = {0};
-    uint64_t seg_scr_off[kNumClasses] = {0}, seg_redo_off[kNumClasses] = {0}, seg_scr_tot = 0, seg_redo_tot = 0;
+    unsigned const seg_stride = lmax_scan + 2u; // rows of 16 bytes per column
+    uint64_t const kSegColBytes = c->seg_col_bytes;
+    unsigned seg_blocks[kNumClasses] = {0}, seg_chunk[kNumClasses] = {0};
+    uint64_t seg_redo_off[kNumClasses] = {0}, seg_col_rows = 0, seg_redo_tot = 0;
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned const np = c->class_first[k + 1] - c->class_first[k];
@@ -1373,24 +1376,30 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         // (from about 32 queries on: below, a pair's segments one after the other are a longer serial chain than the
         // exact kernel's wavefronts side by side -- 1 query 11.8 -> 14.4 ms, 16 queries 79 -> 81, 64: 252 -> 247)
         bool const want = c->seg_mode == 1 || (c->seg_mode < 0 && nq >= 32u);
-        bool const have = sc.W > 1 && sc.R == 3 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
+        bool const have = dcp_segsweep_nodes_per_lane(sc.R, sc.W) != 0 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
         if (!have) continue;
-        uint64_t nb = std::min<uint64_t>((pairs + 3u) / 4u, (uint64_t)dcp_segsweep_blocks_per_cu() * c->num_cus);
+        // queries per chunk: np x chunk pairs x 2 columns x seg_stride x 16 bytes within the cap
+        uint64_t const per_query = (uint64_t)np * 2u * seg_stride * 16u;
+        uint64_t const chunk = std::min<uint64_t>(nq, kSegColBytes / per_query);
+        if (chunk == 0) continue; // very long sequences: the exact kernel
+        uint64_t nb = std::min<uint64_t>((np * chunk + 3u) / 4u, (uint64_t)dcp_segsweep_blocks_per_cu() * c->num_cus);
         nb = (nb + 7u) / 8u * 8u;
-        uint64_t const scr = nb * 4u * seg_stride * 4u; // floats
-        if ((seg_scr_tot + scr) * sizeof(float) > ((uint64_t)8 << 30)) continue; // very long sequences: the exact kernel
         seg_blocks[k] = (unsigned)nb;
-        seg_scr_off[k] = seg_scr_tot, seg_scr_tot += scr;
+        seg_chunk[k] = (unsigned)chunk;
+        // (classes run one after the other on a stream, or side by side on their own streams when the scan is small:
+        // every class gets columns of its own)
+        seg_col_rows += (uint64_t)np * chunk * 2u * seg_stride;
         seg_redo_off[k] = seg_redo_tot, seg_redo_tot += pairs;
     }
-    if (seg_scr_tot)
+    if (seg_col_rows)
     {
-        if (c->d_seg_scratch.n < seg_scr_tot) HIP_TRY(c, c->d_seg_scratch.alloc((size_t)seg_scr_tot));
+        if (c->d_seg_scratch.n < seg_col_rows * 4u) HIP_TRY(c, c->d_seg_scratch.alloc((size_t)seg_col_rows * 4u));
         if (c->d_seg_redo.n < seg_redo_tot) HIP_TRY(c, c->d_seg_redo.alloc((size_t)seg_redo_tot));
         if (!c->d_seg_redo_n.p) HIP_TRY(c, c->d_seg_redo_n.alloc(DCP_MAX_CLASSES));
         HIP_TRY(c, hipMemsetAsync(c->d_seg_redo_n.p, 0, DCP_MAX_CLASSES * sizeof(unsigned), c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream)); // the forked streams wait for the counters' reset too
     }
+    uint64_t seg_col_at = 0; // floats
     for (int k = 0; k < kNumClasses; ++k)
     {
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
@@ -1405,13 +1414,27 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         if (ntasks > 0xffffffffull) return c->fail(DCP_EINVAL, "scan too large for one launch");
         if (seg_blocks[k])
         {
-            a.seg_scratch = c->d_seg_scratch.p + seg_scr_off[k];
+            unsigned const np = a.nprof, chunk = seg_chunk[k];
+            int const segR = dcp_segsweep_nodes_per_lane(sc.R, sc.W);
+            unsigned const nseg_max = (sc.cap() + 64u * (unsigned)segR - 1u) / (64u * (unsigned)segR);
+            a.seg_col0 = c->d_seg_scratch.p + seg_col_at;
+            a.seg_col1 = a.seg_col0 + (size_t)np * chunk * seg_stride * 4u;
+            seg_col_at += (uint64_t)np * chunk * 2u * seg_stride * 4u;
             a.seg_stride = seg_stride;
             a.seg_redo = c->d_seg_redo.p + seg_redo_off[k];
             a.seg_redo_n = c->d_seg_redo_n.p + k;
             a.seg_redo_cap = (unsigned)ntasks;
-            if (dcp_launch_segsweep(sc.R, sc.W, &a, seg_blocks[k], ls))
-                return c->fail(DCP_EFAIL, "no segmented kernel for class R=%d W=%d", sc.R, sc.W);
+            // segment-major: launch s sweeps segment s of every pair of the chunk; the kernel boundary is the hand-off
+            for (unsigned qc = 0; qc < nq; qc += chunk)
+            {
+                a.seg_q0 = qc, a.seg_nq = std::min(chunk, nq - qc);
+                for (unsigned sg = 0; sg < nseg_max; ++sg)
+                {
+                    a.seg_index = sg;
+                    if (dcp_launch_segsweep(sc.R, sc.W, &a, seg_blocks[k], ls))
+                        return c->fail(DCP_EFAIL, "no segmented kernel for class R=%d W=%d", sc.R, sc.W);
+                }
+            }
             HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
             c->launched_redo[c->n_launched] = false;
             c->launched_class[c->n_launched++] = k;
@@ -1491,6 +1514,12 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
     c->rs_force_R = (int)((bw >> 20) & 15u);      // bits 20..23: only the class with this many nodes per lane (0: all)
     c->seg_mode = ((bw >> 24) & 3u) == 1u ? 0 : ((bw >> 24) & 3u) == 2u ? 1 : -1; // bits 24..25: 1 = never the segmented sweep, 2 = always
+    return DCP_OK;
+}
+int dcp_gpu_test_set_seg_col_bytes(dcp_gpu_ctx *c, unsigned long long bytes)
+{
+    if (!c) return DCP_EINVAL;
+    c->seg_col_bytes = bytes ? bytes : (uint64_t)6 << 30;
     return DCP_OK;
 }
 int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *c, int on)

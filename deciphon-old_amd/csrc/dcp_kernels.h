@@ -57,10 +57,14 @@ struct dcp_scan_args
     dcp_pair const *pairs;
     unsigned const *npairs;
     unsigned pair_cap;
-    // segmented sweep of a multi-wavefront class (viterbi_segsweep_kernel): per-wavefront scratch columns of
-    // seg_stride float4 (two halves of lmax + 2 rows), and the list of the pairs it hands to the exact kernel
-    float *seg_scratch;
-    unsigned seg_stride;
+    // segmented sweep of a multi-wavefront class (viterbi_segment_kernel, one segment per launch): the pairs' boundary
+    // columns -- pair (profile s_rel of the class, query q) owns column s_rel * nseqs + q of seg_stride float4 in each
+    // of the two buffers; segment s reads the one segment s - 1 wrote (col0 for odd s) and writes the other -- and
+    // the list of the pairs the last segment hands to the exact kernel
+    float *seg_col0, *seg_col1; // 16 bytes per row
+    unsigned seg_stride; // rows (of 16 bytes) per column, >= lmax + 2
+    unsigned seg_index;  // this launch's segment
+    unsigned seg_q0, seg_nq; // the queries of this launch: q = seg_q0 .. seg_q0 + seg_nq - 1 (a chunk of the scan's, sized so that the columns fit)
     dcp_pair *seg_redo;
     unsigned *seg_redo_n;
     unsigned seg_redo_cap;
@@ -195,8 +199,9 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
-// one wavefront per pair over the segments of a profile of a multi-wavefront class; != 0: no such kernel
+// segment a->seg_index of every pair of a multi-wavefront class, one wavefront per pair; != 0: no such kernel
 int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
+int dcp_segsweep_nodes_per_lane(int R, int W); // nodes per lane of that class's segments (0: none)
 unsigned dcp_segsweep_blocks_per_cu(void); // resident 256-thread blocks per CU of that kernel
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large

@@ -887,36 +887,62 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
 }
 
 // ============================================================================
-// Segmented sweep: one wavefront per (profile, query) pair of a multi-wavefront size class, the profile cut into
-// segments of 64 x R nodes that the wavefront sweeps one after the other (seg_row above).  Grid mode only; a
-// persistent grid strides over the class's profiles x queries.  Pairs with E -> B / J -> B feedback, and all pairs
-// of a profile flagged DCP_PROF_EXACT_E, are appended to `seg_redo` for the exact kernel (pair mode), which runs
-// right behind on the same stream.  Each wavefront owns a scratch column of 2 x (lmax + 2) rows of 16 bytes.
+// Segmented sweep, SEGMENT-MAJOR (round 4): one wavefront per (profile, query) pair of a multi-wavefront size class,
+// the profile cut into segments of 64 x R nodes (seg_row above) -- but ONE SEGMENT PER LAUNCH: launch s sweeps segment
+// s of every pair of the class over all rows, reading what segment s - 1 left for each row (M, I, D of its last node,
+// E so far: 16 bytes) from the pair's boundary column in HBM and writing its own to the other column of the pair.
+// Why: round 3's kernel swept a pair's segments back to back, so an XCD's wavefronts were in both segments of a
+// 768-column profile at once -- a 4.2 MB table against a 4 MB L2, hit rate 0.77, 0.6 of the one-wavefront R = 6
+// class's rate (profiles/r03/c3_rowsweep_segsweep_pmc_derived.txt).  Segment-major, the pairs an XCD works on share
+// ONE segment's table (2.1 MB at R = 6, 2.8 MB at R = 8), the working set of a one-wavefront class.  The kernel
+// boundary is the hand-off between segments: the column a launch reads was written by the launch before it, so there
+// is no intra-kernel store -> scalar-load ordering to rely on (ADVICE r3 on round 3's form).
+// Grid mode only; a persistent grid strides over the class's profiles x queries.  The LAST segment's launch has
+// E(j) and J(j): pairs with E -> B / J -> B feedback, and all pairs of a profile flagged DCP_PROF_EXACT_E, are
+// appended to `seg_redo` for the exact kernel (pair mode), which runs behind it on the same stream.
 // ============================================================================
 #ifndef DCP_SEG_WAVES
 #define DCP_SEG_WAVES 2
 #endif
 template <int R>
-__global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segsweep_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp_scan_args a)
 {
     unsigned const lane = threadIdx.x & 63u;
     unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned const nblk = gridDim.x; // multiple of 8
     unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
     unsigned const gwave = vblk * 4u + wave;
-    unsigned const ntasks = a.nprof * a.nseqs;
-    float4 *const scr = reinterpret_cast<float4 *>(a.seg_scratch) + (size_t)gwave * a.seg_stride; // [2][seg_stride / 2]
-    unsigned const half = a.seg_stride >> 1;
+    unsigned const ntasks = a.nprof * a.seg_nq;
+    unsigned const seg = a.seg_index; // this launch's segment
     float const ni = neg_inf();
-    for (unsigned task = gwave; task < ntasks; task += nblk * 4u)
+    // XCD-aware task map as in the row sweep: an XCD's blocks take one contiguous range of tasks = consecutive
+    // queries of the same few profiles, whose segment table then stays in that XCD's L2
+    unsigned const per_x = (ntasks + 7u) / 8u;
+    unsigned const xcd = blockIdx.x & 7u, wx = (blockIdx.x >> 3) * 4u + wave, nwx = (nblk >> 3) * 4u;
+    (void)gwave;
+    for (unsigned ti = wx; ti < per_x; ti += nwx)
     {
-        unsigned const s_rel = task / a.nseqs;
+        unsigned const task = xcd * per_x + ti;
+        if (task >= ntasks) break;
+        unsigned const s_rel = task / a.seg_nq;
         unsigned const slot = __builtin_amdgcn_readfirstlane(a.first_prof + s_rel);
-        unsigned const q = __builtin_amdgcn_readfirstlane(task - s_rel * a.nseqs);
+        unsigned const q = __builtin_amdgcn_readfirstlane(a.seg_q0 + (task - s_rel * a.seg_nq));
         dcp_prof_meta const pm = a.profs[slot];
-        unsigned const ldk = pm.ldk; // core_size + 8 rounded up to 4, at most the class capacity (a multiple of 64 x R)
+        unsigned const ldk = pm.ldk; // core_size + 8 rounded up to 4, at most the class capacity
         unsigned const nseg = (pm.core_size + 64u * R - 1u) / (64u * R);
-        bool dirty = (pm.flags & DCP_PROF_EXACT_E) != 0u;
+        if (seg >= nseg) continue; // a shorter profile of the class: done in an earlier launch
+        bool const last = seg + 1u == nseg;
+        bool const flagged = (pm.flags & DCP_PROF_EXACT_E) != 0u;
+        if (flagged)
+        {
+            // E(j) is not the match states' maximum for this profile: the exact kernel scores all its pairs
+            if (last && lane == 0u)
+            {
+                unsigned const h = atomicAdd(a.seg_redo_n, 1u);
+                if (h < a.seg_redo_cap) a.seg_redo[h] = dcp_pair{q, slot};
+            }
+            continue;
+        }
         float const *__restrict__ em_prof = a.emis_match + pm.emis_off;
         cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
         cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
@@ -932,59 +958,52 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segsweep_kernel(dc
         float xEB = xt[DCP_X_EB];
         asm volatile("" : "+v"(xEB));
         RowOut o{ni, ni};
-        for (unsigned seg = 0; seg < nseg && !dirty; ++seg) // `dirty` is wave-uniform
+        unsigned const node0 = seg * 64u * R + lane * R;
+        unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the -inf tail
+        float const *__restrict__ em_base = em_prof; // wave-uniform; the lane's columns through lane_boff
+        Trans<R> t;
         {
-            bool const last = seg + 1u == nseg;
-            unsigned const node0 = seg * 64u * R + lane * R;
-            unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the -inf tail
-            float const *__restrict__ em_base = em_prof; // wave-uniform; the lane's columns through lane_boff
-            Trans<R> t;
-            {
-                float const *__restrict__ tb = a.trans8 + pm.trans_off + lane_off;
-                VecLoad<R>::ld(tb + (size_t)DCP_T_ENTRY * ldk, t.ent);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_MM * ldk, t.mm);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_IM * ldk, t.im);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_DM * ldk, t.dm);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_MD * ldk, t.md);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_DD * ldk, t.dd);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_MI * ldk, t.mi);
-                VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
-            }
-            // The previous segment's boundary column is read with SCALAR loads (the row's values are wave-uniform and
-            // only lane 0 needs them as operands): they count on lgkmcnt with the row's other scalar loads, so waiting
-            // for them never drains the emission rows in flight (as vector loads, a copy of the just-loaded values at
-            // the end of every row did: vmcnt(0)).  The column was written by this wavefront's vector stores: they are
-            // complete (in this XCD's L2, which the scalar cache reads from) after a workgroup-scope release fence --
-            // s_waitcnt vmcnt(0); an agent-scope one would write the whole L2 back (buffer_wbl2), twice per pair --
-            // and the scalar cache drops what it may hold of an earlier use of the scratch.
-            cfloat *bsrc = as_const(reinterpret_cast<float const *>(scr + (seg & 1u ? 0u : half))); // what s - 1 wrote
-            float4 *bdst = scr + (seg & 1u ? half : 0u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_dcache_inv();
-            PairState<R> s;
+            float const *__restrict__ tb = a.trans8 + pm.trans_off + lane_off;
+            VecLoad<R>::ld(tb + (size_t)DCP_T_ENTRY * ldk, t.ent);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_MM * ldk, t.mm);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_IM * ldk, t.im);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_DM * ldk, t.dm);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_MD * ldk, t.md);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_DD * ldk, t.dd);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_MI * ldk, t.mi);
+            VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
+        }
+        // The pair's boundary columns: row j's {m, i, d, e} at [j].  What segment s - 1 wrote is read with SCALAR
+        // loads (wave-uniform values that only lane 0 needs as operands: they count on lgkmcnt with the row's other
+        // scalar loads, so waiting for them never drains the emission rows in flight); it was written by the launch
+        // before this one.  Segment s writes the pair's other column.
+        size_t const col = (size_t)task * a.seg_stride;
+        cfloat *bsrc = as_const((seg & 1u ? a.seg_col1 : a.seg_col0) + 4u * col);
+        float4 *bdst = reinterpret_cast<float4 *>(seg & 1u ? a.seg_col0 : a.seg_col1) + col;
+        PairState<R> s;
 #pragma unroll
-            for (int h = 0; h < 5; ++h)
-            {
+        for (int h = 0; h < 5; ++h)
+        {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    s.P[h][r] = ni, s.Q[h][r] = ni;
-                s.PX[h] = ni;
-            }
-            {
-                float const B0 = 0.0f + xt[DCP_X_SB];
+            for (int r = 0; r < R; ++r)
+                s.P[h][r] = ni, s.Q[h][r] = ni;
+            s.PX[h] = ni;
+        }
+        {
+            float const B0 = 0.0f + xt[DCP_X_SB];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    s.P[0][r] = B0 + t.ent[r];
-                s.PX[0] = x == 0u ? 0.0f + xt[DCP_X_SN] : x == 3u ? 0.0f : ni;
-            }
-            float em[5][R], eN[5], eI[5];
-            unsigned w = base_at(words, 0);
-            unsigned lane_boff = lane_off * 4u;
-            load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr);
-            SegBnd bnd{ni, ni, ni, ni}, bnx{ni, ni, ni, ni};
-            if (seg > 0u) bnd = SegBnd{bsrc[4], bsrc[5], bsrc[6], bsrc[7]}; // row 1
-            unsigned j = 1;
-            bool seg_dirty = false;
+            for (int r = 0; r < R; ++r)
+                s.P[0][r] = B0 + t.ent[r];
+            s.PX[0] = x == 0u ? 0.0f + xt[DCP_X_SN] : x == 3u ? 0.0f : ni;
+        }
+        float em[5][R], eN[5], eI[5];
+        unsigned w = base_at(words, 0);
+        unsigned lane_boff = lane_off * 4u;
+        load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr);
+        SegBnd bnd{ni, ni, ni, ni}, bnx{ni, ni, ni, ni};
+        if (seg > 0u) bnd = SegBnd{bsrc[4], bsrc[5], bsrc[6], bsrc[7]}; // row 1
+        unsigned j = 1;
+        bool seg_dirty = false;
 #define DCP_SROW(PH, LASTSEG)                                                                      \
     {                                                                                             \
         w = ((w << 2) | base_at(words, j)) & 1023u;                                               \
@@ -996,32 +1015,31 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segsweep_kernel(dc
         bnd = bnx;                                                                                \
         ++j;                                                                                      \
     }
-            if (last)
+        if (last)
+        {
+            while (j + 4 <= L)
             {
-                while (j + 4 <= L)
-                {
-                    DCP_SROW(1, true) DCP_SROW(2, true) DCP_SROW(3, true) DCP_SROW(4, true) DCP_SROW(0, true)
-                }
-                if (j <= L) DCP_SROW(1, true)
-                if (j <= L) DCP_SROW(2, true)
-                if (j <= L) DCP_SROW(3, true)
-                if (j <= L) DCP_SROW(4, true)
+                DCP_SROW(1, true) DCP_SROW(2, true) DCP_SROW(3, true) DCP_SROW(4, true) DCP_SROW(0, true)
             }
-            else
-            {
-                while (j + 4 <= L)
-                {
-                    DCP_SROW(1, false) DCP_SROW(2, false) DCP_SROW(3, false) DCP_SROW(4, false) DCP_SROW(0, false)
-                }
-                if (j <= L) DCP_SROW(1, false)
-                if (j <= L) DCP_SROW(2, false)
-                if (j <= L) DCP_SROW(3, false)
-                if (j <= L) DCP_SROW(4, false)
-            }
-#undef DCP_SROW
-            dirty = dirty || __any(seg_dirty);
+            if (j <= L) DCP_SROW(1, true)
+            if (j <= L) DCP_SROW(2, true)
+            if (j <= L) DCP_SROW(3, true)
+            if (j <= L) DCP_SROW(4, true)
         }
-        if (dirty)
+        else
+        {
+            while (j + 4 <= L)
+            {
+                DCP_SROW(1, false) DCP_SROW(2, false) DCP_SROW(3, false) DCP_SROW(4, false) DCP_SROW(0, false)
+            }
+            if (j <= L) DCP_SROW(1, false)
+            if (j <= L) DCP_SROW(2, false)
+            if (j <= L) DCP_SROW(3, false)
+            if (j <= L) DCP_SROW(4, false)
+        }
+#undef DCP_SROW
+        if (!last) continue;
+        if (__any(seg_dirty)) // wave-uniform
         {
             if (lane == 0u)
             {
@@ -1637,17 +1655,19 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
 }
 
 extern "C" unsigned dcp_segsweep_blocks_per_cu(void) { return DCP_SEG_WAVES; } // four-wavefront blocks: its waves per SIMD
+// nodes per lane of a segment of the (R, W) multi-wavefront class: 6 (384-node segments) for the R = 3 classes, 8
+// (512-node segments) for the R = 4 ones -- the classes' capacities are multiples of those; 0: no segmented kernel
+extern "C" int dcp_segsweep_nodes_per_lane(int R, int W) { return W > 1 ? (R == 3 ? 6 : R == 4 ? 8 : 0) : 0; }
 
-// Segmented sweep of a multi-wavefront class whose capacity is a multiple of 64 x R (R = 6: the R = 3 classes);
-// != 0 if there is no such kernel.  seg_scratch must hold nblocks x 4 columns of a->seg_stride float4.
+// One launch = segment a->seg_index of every (profile, query) pair of a multi-wavefront class (viterbi_segment_kernel);
+// != 0 if there is no such kernel.  a->seg_col0 / seg_col1: the pairs' boundary columns, a->seg_stride float4 each.
 extern "C" int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream)
 {
-    if (R == 3 && W > 1)
-    {
-        hipLaunchKernelGGL((viterbi_segsweep_kernel<6>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
-        return 0;
-    }
-    return -1;
+    int const r = dcp_segsweep_nodes_per_lane(R, W);
+    if (r == 6) hipLaunchKernelGGL((viterbi_segment_kernel<6>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (r == 8) hipLaunchKernelGGL((viterbi_segment_kernel<8>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
+    else return -1;
+    return 0;
 }
 
 // unstaged kernels: pair mode (a->pairs), the classes of several wavefronts per pair, and grid mode without staging

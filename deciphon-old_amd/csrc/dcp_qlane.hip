@@ -241,8 +241,6 @@ struct LdsLink
     unsigned my_flag;      // byte offset of this stage's flag array (wave-uniform)
     unsigned peer_flag;    // byte offset of the partner wavefront's lane-0 flag (wave-uniform)
     unsigned seen;         // wave-uniform: the partner's progress as last read
-    unsigned dead;         // wave-uniform: a wait of this wavefront ran into kRingSpinBound (ring_wait)
-    unsigned *error;       // the scan's error word (dcp_qlane_args::ring_error)
 };
 // Block LDS of the two-stage kernel: all 160 KiB, laid out so that EVERY access keeps an immediate
 // offset.  Gathers address a tile image as (window bits) + 16-bit immediate: image 0 sits at 0, image 1
@@ -254,6 +252,8 @@ constexpr unsigned kL2FlagP = kL2TabIN + 2u * 1364u * 4u; // 54 560: producer fl
 constexpr unsigned kL2FlagC = kL2FlagP + kRLanes * 4u;
 constexpr unsigned kL2Null = kL2FlagC + kRLanes * 4u;    // (round 2-3: null scores, stage 0 -> final stage; now parked in the planes)
 constexpr unsigned kL2Task = kL2Null + kRLanes * 4u;     // the task word
+constexpr unsigned kL2Abort = kL2Task + 4u;              // != 0: a wavefront of this block ran into the ring's poll bound during this task
+constexpr unsigned kL2Err = kL2Task + 8u;                // the address of the scan's error word (8 bytes), for ring_wait
 constexpr unsigned kL2Tab1 = 65536u;                   // image of the odd tile
 constexpr unsigned kL2Ring = 7u * kRingPlaneBytes;     // 114 688 .. 163 840
 constexpr unsigned kL2Bytes = kL2Ring + 3u * kRingPlaneBytes;
@@ -285,42 +285,50 @@ __device__ __forceinline__ void flag_store(lds_uint *flag, unsigned v)
 }
 // Polls are BOUNDED: the only hang this kernel has ever produced came from this loop (an
 // experimental 8-row ring, round 3), and a hung GPU costs a whole lease.  A legitimate wait is a few rows of the
-// partner's work -- microseconds; kRingSpinBound polls of >= 0.1 us each are a second.  A wavefront that runs into
-// the bound sets the scan's error word and marks its end of the ring dead: from then on it waits for nothing (its
-// rows are garbage, the scan is failed as a whole by dcp_gpu_sync), its partner runs into its own bound at worst
-// once, and the grid drains.
+// partner's work -- microseconds; kRingSpinBound polls of >= 0.1 us each are a second.  A wavefront that runs into the
+// bound sets the scan's error word (dcp_gpu_sync then fails the scan as a whole) and POISONS the flag it polls with
+// a row number no sweep reaches: every later wait of this step passes at its first read -- the state "dead" lives in
+// the LDS word, not in a register of the row loops.  (A first form kept it in the LdsLink and carried the error
+// word's address with it: three more scalar registers live through six inlined sweeps cost the C3 launch 1.7 %; a
+// second form read the global error word at every step, in front of the step's barrier: 0.9 % --
+// profiles/r04/ring_bound_ab.txt.)  The address of the error word waits in LDS (kL2Err) for the slow path; the
+// wavefront also sets the block's kL2Abort word, which every step checks behind its barrier (an LDS read), so the
+// block's task winds down without sweeping; and no block takes another task once the global word is set (read
+// together with the task counter's atomic): the grid drains.
 #ifndef DCP_Q2_BOUND
-#define DCP_Q2_BOUND 1 // 0: the unbounded loop of rounds 2-3 (pricing builds only: profiles/r04/ring_bound_ab.txt)
+#define DCP_Q2_BOUND 1 // 0: the unbounded loop of rounds 2-3 (pricing builds only)
 #endif
-[[maybe_unused]] constexpr unsigned kRingSpinBound = 1u << 23;
-__device__ __forceinline__ unsigned ring_wait(LdsLink &lk, unsigned need)
+constexpr unsigned kRingSpinBound = 1u << 23;
+constexpr unsigned kRingPoison = 0x7fffff00u;
+__device__ __forceinline__ unsigned ring_wait(LdsLink const &lk, unsigned need)
 {
     lds_uint *flag = (lds_uint *)(lk.base + lk.peer_flag);
     unsigned v = __builtin_amdgcn_readfirstlane(flag_load(flag));
 #if DCP_Q2_BOUND
     unsigned spins = 0;
+#pragma nounroll
     while (v < need)
     {
-        if (lk.dead) break;
         __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
         v = __builtin_amdgcn_readfirstlane(flag_load(flag));
-        if (++spins > kRingSpinBound)
+        if (__builtin_expect(++spins == kRingSpinBound, 0))
         {
-            lk.dead = 1u;
-            __hip_atomic_store(lk.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned *const err = *(unsigned *__attribute__((address_space(3))) *)(lk.base + kL2Err);
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag_store((lds_uint *)(lk.base + kL2Abort), 1u); // this block's task winds down at its next step
+            flag_store(flag, kRingPoison);
+            v = kRingPoison;
         }
     }
-    DCP_ISA_MARK("DCP_RING_ACQUIRED"); // acquire: the ring reads that follow stay behind the flag read
-    return lk.dead ? 0x7fffff00u : v; // dead: every later check of this sweep passes
 #else
     while (v < need)
     {
         __builtin_amdgcn_s_sleep(DCP_Q2_SLEEP);
         v = __builtin_amdgcn_readfirstlane(flag_load(flag));
     }
-    DCP_ISA_MARK("DCP_RING_ACQUIRED");
-    return v;
 #endif
+    DCP_ISA_MARK("DCP_RING_ACQUIRED"); // acquire: the ring reads that follow stay behind the flag read
+    return v;
 }
 // boundary values of the row whose scratch-plane byte offset is `rowoff`
 __device__ __forceinline__ float ring_ld(LdsLink const &lk, unsigned rowoff, unsigned plane)
@@ -652,7 +660,7 @@ __device__ __forceinline__ void ql_sweep(cfloat *tt, float const *tabM, float2 c
                                          uint32_t const *__restrict__ wordsT, unsigned rowbase,
                                          unsigned L, unsigned Lwave, bool active, float *sc,
                                          size_t plane, unsigned tid, LaneXt const &xt, bool &dirty,
-                                         SweepOut &o, LdsLink &lk
+                                         SweepOut &o, LdsLink lk
 #if DCP_QLANE_DIAG & 4
                                          , unsigned tile_odd
 #endif
@@ -936,7 +944,6 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
     size_t const plane = (size_t)a.plane_rows * (unsigned)NT;
     float *const sc = a.scratch + (size_t)blockIdx.x * kPlanes * plane; // wave-uniform base
     constexpr unsigned SLOTS = (unsigned)NT / 64u;
-    LdsLink nolink{};
 
     for (;;)
     {
@@ -994,7 +1001,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 #define QL_DIAG4_TILE
 #endif
 #define QL_SWEEP(F, L_)                                                                          \
-    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, nolink QL_DIAG4_TILE)
+    ql_sweep<G, F, L_, NT, D>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, LdsLink{} QL_DIAG4_TILE)
                 if (first && last) QL_SWEEP(true, true);
                 else if (first) QL_SWEEP(true, false);
                 else if (last) QL_SWEEP(false, true);
@@ -1058,12 +1065,19 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     lk.my_flag = stage == 0u ? kL2FlagP : kL2FlagC;
     lk.peer_flag = (stage == 0u ? kL2FlagC : kL2FlagP) + (tid & ~63u) * 4u;
     lk.seen = 0u;
-    lk.dead = 0u;
-    lk.error = a.ring_error;
+    if (threadIdx.x == 0) *(unsigned **)(lds + kL2Err / 4u) = a.ring_error;
+    unsigned *const s_abort_p = reinterpret_cast<unsigned *>(lds + kL2Abort / 4u);
 
     for (;;)
     {
-        if (threadIdx.x == 0) *s_task_p = atomicAdd(a.task_counter, 1u);
+        // (once the error word is set no block takes another task: the grid drains; load and atomic are in flight together)
+        if (threadIdx.x == 0)
+        {
+            unsigned const failed = __hip_atomic_load(a.ring_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned const next = atomicAdd(a.task_counter, 1u);
+            *s_task_p = failed ? 0xffffffffu : next;
+            *s_abort_p = 0u;
+        }
         __syncthreads();
         unsigned const task = __builtin_amdgcn_readfirstlane(*s_task_p);
         __syncthreads();
@@ -1106,7 +1120,8 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
             }
             flag_store((lds_uint *)(lk.base + lk.my_flag + tid * 4u), 0u); // row counters restart with every step
             __syncthreads();
-            if (!mine || (stalled && st == 0u)) continue;
+            // (the scan has failed -- some wavefront's hand-shake ran into its bound: no more sweeps, the task winds down)
+            if (!mine || (stalled && st == 0u) || __builtin_amdgcn_readfirstlane(*s_abort_p) != 0u) continue;
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0u, last = t + 1u == T;
 #if DCP_QLANE_DIAG & 4
@@ -1192,7 +1207,6 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
     float2 *const tabIN = reinterpret_cast<float2 *>(tabM + TAB_FLOATS);
     size_t const plane = (size_t)a.plane_rows * (unsigned)NT;
     float *const sc = a.scratch + ((size_t)blockIdx.x * 3u + wv) * kPlanes * plane;
-    LdsLink nolink{};
 
     for (;;)
     {
@@ -1237,7 +1251,7 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
                 SweepOut o{ninf(), ninf(), ninf()};
                 bool dirty = false;
 #define QLW_SWEEP(F, L_)                                                                                  \
-    ql_sweep<G, F, L_, NT, D, IO_HBM, IO_HBM, 0u, false>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, nolink)
+    ql_sweep<G, F, L_, NT, D, IO_HBM, IO_HBM, 0u, false>(tt, tabM, tabIN, wordsT, g.rowbase, g.L, g.Lwave, g.has, sc, plane, tid, g.xt, dirty, o, LdsLink{})
                 if (first && last) QLW_SWEEP(true, true);
                 else if (first) QLW_SWEEP(true, false);
                 else if (last) QLW_SWEEP(false, true);

@@ -307,6 +307,9 @@ int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *, unsigned cap);
  * step, so its partner stage runs into the bound of the LDS ring's hand-shake: the kernel must drain and
  * dcp_gpu_sync must return DCP_EFAIL (never a hang). */
 int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *, int on);
+/* Same build only.  Cap in bytes on the boundary columns the segmented row sweep keeps per size class (0 restores the
+ * default, 6 GiB): a small cap makes it sweep a class's queries chunk by chunk. */
+int dcp_gpu_test_set_seg_col_bytes(dcp_gpu_ctx *, unsigned long long bytes);
 /* Same build only.  Forces the grid-mode row-sweep kernel variant -- leading emission rows a block stages in
  * LDS (0, 20 or 84) and, in `block_waves`: bits 0..7 wavefronts per block (0: the default), bits 8..15 KiB of
  * unused LDS per block (an occupancy experiment), bit 16 the two-rows-ahead prefetch variant, bits 20..23 the

@@ -650,15 +650,18 @@ def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves,
 
 @pytest.mark.parametrize("multi", [True, False])
 def test_segmented_sweep_bit_exact(dcp, oracle32, hooks_scanner, multi):
-    """Profiles of more than 512 nodes in grid mode: one wavefront per pair sweeps the profile's 384-node segments one
-    after the other with B(j) = N(j) + NB (viterbi_segsweep_kernel), and the pairs whose E -> B / J -> B feedback
-    beat that B -- planted hits here -- are finished by the exact multi-wavefront kernel behind it.  Forced on for
-    every batch size through the test-hooks build (the library uses it from 32 queries on), against the oracle's
-    float32 recursion on the product's tables, bit for bit; a flagged (positive MD / DD) profile goes to the exact
-    kernel whole.  Classes without a segmented kernel (769..1024, 1537..2048 nodes) run beside it."""
+    """Profiles of more than 512 nodes in grid mode: one wavefront per pair, the profile cut into segments of 384 nodes
+    (the R = 3 multi-wavefront classes) or 512 nodes (the R = 4 ones), ONE SEGMENT PER LAUNCH with the pair's boundary
+    column parked in HBM between launches (viterbi_segment_kernel), B(j) = N(j) + NB, and the pairs whose E -> B /
+    J -> B feedback beat that B -- planted hits here, in a 384- and in a 512-node-segment class -- finished by the exact
+    multi-wavefront kernel behind it.  Forced on for every batch size through the test-hooks build (the library uses it
+    from 32 queries on), against the oracle's float32 recursion on the product's tables, bit for bit; every multi-
+    wavefront class at both ends of its range (two to eight segments; profiles of one class with different segment
+    counts side by side); a flagged (positive MD / DD) profile goes to the exact kernel whole; with a column budget of a
+    few hundred KB a class's queries are swept chunk by chunk."""
     rng = np.random.default_rng(9090 + int(multi))
     cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
-    sizes = (513, 600, 767, 768, 900, 1100, 1536, 1700, 2500, 3072, 300)
+    sizes = (513, 600, 767, 768, 769, 900, 1024, 1025, 1100, 1536, 1537, 1700, 2048, 2049, 2500, 3072, 3073, 3600, 4096, 300)
     params = [pfam_like_params(rng, M) for M in sizes]
     null, match, trans = pfam_like_params(rng, 640)
     trans = trans.copy()
@@ -671,23 +674,31 @@ def test_segmented_sweep_bit_exact(dcp, oracle32, hooks_scanner, multi):
         prof_eps[id(pr)] = cfg.epsilon
     hooks_scanner.upload_db(profiles, expand_on_host=True)
     try:
-        for nseq in (1, 5, 37):
+        for nseq, col_bytes in ((1, 0), (5, 0), (37, 0), (37, 300 << 10)):
             seqs = rand_seqs(rng, nseq, 1, 260)
             if nseq > 1:  # homologous queries: the multi-hit feedback path
-                seqs[0] = planted_query(rng, oprofs[1], sizes[1], flank=15)
-                seqs[-1] = planted_query(rng, oprofs[6], sizes[6], flank=9)
+                seqs[0] = planted_query(rng, oprofs[1], sizes[1], flank=15)   # 600 nodes: two 384-node segments
+                seqs[-1] = planted_query(rng, oprofs[8], sizes[8], flank=9)   # 1100 nodes: three
+                seqs[2] = planted_query(rng, oprofs[5], sizes[5], flank=11)   # 900 nodes: two 512-node segments
             hooks_scanner.upload_seqs(seqs)
+            hooks_scanner.test_set_seg_col_bytes(col_bytes)
             hooks_scanner.test_set_rowsweep_variant(20, 4 | (2 << 24))  # segmented sweep: always
             hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
             gn, ga = hooks_scanner.scores()
+            hits = hooks_scanner.hits()
             on, oa = oracle_dp_on_product_tables(dcp, oracle32, hooks_scanner, profiles, seqs, multi, False, True)
-            assert same_bits(gn, on) and same_bits(ga, oa), (nseq, multi)
+            assert same_bits(gn, on) and same_bits(ga, oa), (nseq, multi, col_bytes)
             hooks_scanner.test_set_rowsweep_variant(20, 4 | (1 << 24))  # the same batch without it
             hooks_scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
             en, ea = hooks_scanner.scores()
             assert same_bits(gn, en) and same_bits(ga, ea)
+            assert np.array_equal(hits, hooks_scanner.hits())
+            if nseq > 1:
+                got = {(int(h["seq_idx"]), int(h["profile_idx"])) for h in hits}
+                assert {(0, 1), (nseq - 1, 8), (2, 5)} <= got
     finally:
         hooks_scanner.test_set_rowsweep_variant(-1, 0)
+        hooks_scanner.test_set_seg_col_bytes(0)
 
 
 def test_qlane_at_block_scale(dcp, oracle32, scanner):
