@@ -1382,9 +1382,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         uint64_t const per_query = (uint64_t)np * 2u * seg_stride * 16u;
         uint64_t const chunk = std::min<uint64_t>(nq, kSegColBytes / per_query);
         if (chunk == 0) continue; // very long sequences: the exact kernel
-        uint64_t nb = std::min<uint64_t>((np * chunk + 3u) / 4u, (uint64_t)dcp_segsweep_blocks_per_cu() * c->num_cus);
-        nb = (nb + 7u) / 8u * 8u;
-        seg_blocks[k] = (unsigned)nb;
+        if ((uint64_t)np * ((chunk + 3u) / 4u) > 0x7ffffff0ull) continue;
+        seg_blocks[k] = dcp_segsweep_blocks(np, (unsigned)chunk);
         seg_chunk[k] = (unsigned)chunk;
         // (classes run one after the other on a stream, or side by side on their own streams when the scan is small:
         // every class gets columns of its own)
@@ -1431,7 +1430,7 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
                 for (unsigned sg = 0; sg < nseg_max; ++sg)
                 {
                     a.seg_index = sg;
-                    if (dcp_launch_segsweep(sc.R, sc.W, &a, seg_blocks[k], ls))
+                    if (dcp_launch_segsweep(sc.R, sc.W, &a, dcp_segsweep_blocks(np, a.seg_nq), ls))
                         return c->fail(DCP_EFAIL, "no segmented kernel for class R=%d W=%d", sc.R, sc.W);
                 }
             }

@@ -202,7 +202,7 @@ unsigned dcp_rowsweep_tasks_per_block(int W);
 // segment a->seg_index of every pair of a multi-wavefront class, one wavefront per pair; != 0: no such kernel
 int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
 int dcp_segsweep_nodes_per_lane(int R, int W); // nodes per lane of that class's segments (0: none)
-unsigned dcp_segsweep_blocks_per_cu(void); // resident 256-thread blocks per CU of that kernel
+unsigned dcp_segsweep_blocks(unsigned nprof, unsigned nq); // grid of one segment launch over nprof profiles x nq queries
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large
 int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, int stg, unsigned bw, void *stream,

@@ -571,8 +571,10 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
                                          unsigned ldk, unsigned &lane_boff,
                                          cfloat *eN_tab, cfloat *eI_tab,
                                          unsigned w, float (&em)[5][R], float (&em3)[R], float (&em4)[R], float (&em5)[R],
-                                         float (&eN)[5], float (&eI)[5], float const *stg)
+                                         float (&eN)[5], float (&eI)[5], float const *stg, unsigned stg_ldk = 0u)
 {
+    // stg_ldk: row length of the staged image when it is not the table's (a segment's columns only); 0 = ldk
+    unsigned const sldk = stg_ldk ? stg_ldk : ldk;
     asm volatile("" : "+v"(lane_boff));
 #pragma unroll
     for (int l = 1; l <= 5; ++l)
@@ -585,7 +587,7 @@ __device__ __forceinline__ void load_row(float const *__restrict__ em_base,
             {
                 // the row's byte offset as ONE scalar value (left alone, the constant part of a two-base word's
                 // row becomes a second per-lane add: ds_read2's offset fields are too narrow for it)
-                unsigned roff = c * ldk * 4u;
+                unsigned roff = c * sldk * 4u;
                 asm volatile("" : "+s"(roff));
                 VecLoad<R>::ld((float const *)((char const *)stg + (roff + lane_boff)), dst);
             }
@@ -901,42 +903,51 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
 // E(j) and J(j): pairs with E -> B / J -> B feedback, and all pairs of a profile flagged DCP_PROF_EXACT_E, are
 // appended to `seg_redo` for the exact kernel (pair mode), which runs behind it on the same stream.
 // ============================================================================
-#ifndef DCP_SEG_WAVES
-#define DCP_SEG_WAVES 2
+// Like the one-wavefront classes' large-batch kernels, a block is four wavefronts scoring consecutive queries
+// against ONE profile's segment, whose 20 leading emission rows (the one- and two-base words: two of a row's five
+// reads) they copy to LDS together -- the segment's 64 x R columns plus the few of the row's -inf tail a lane past
+// the last node points at.  R = 6 runs three wavefronts per SIMD (168 VGPRs) like R6W1's large-batch variant.
+#ifndef DCP_SEG_WAVES6
+#define DCP_SEG_WAVES6 3
 #endif
+#ifndef DCP_SEG_WAVES8
+#define DCP_SEG_WAVES8 2
+#endif
+constexpr int kSegStaged = 20;      // rows of the segment's image in LDS
+constexpr unsigned kSegStagePad = 8; // columns past the segment's 64 x R that a staged row also holds
 template <int R>
-__global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(256, R == 6 ? DCP_SEG_WAVES6 : DCP_SEG_WAVES8) void viterbi_segment_kernel(dcp_scan_args a)
 {
+    constexpr unsigned SLD = 64u * R + kSegStagePad; // floats per staged row
+    __shared__ __attribute__((aligned(16))) float stage_mem[kSegStaged * SLD];
     unsigned const lane = threadIdx.x & 63u;
     unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned const nblk = gridDim.x; // multiple of 8
-    unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-    unsigned const gwave = vblk * 4u + wave;
-    unsigned const ntasks = a.nprof * a.seg_nq;
-    unsigned const seg = a.seg_index; // this launch's segment
-    float const ni = neg_inf();
-    // XCD-aware task map as in the row sweep: an XCD's blocks take one contiguous range of tasks = consecutive
+    // XCD-aware block map as in the row sweep: an XCD's blocks take one contiguous range of tasks = consecutive
     // queries of the same few profiles, whose segment table then stays in that XCD's L2
-    unsigned const per_x = (ntasks + 7u) / 8u;
-    unsigned const xcd = blockIdx.x & 7u, wx = (blockIdx.x >> 3) * 4u + wave, nwx = (nblk >> 3) * 4u;
-    (void)gwave;
-    for (unsigned ti = wx; ti < per_x; ti += nwx)
+    unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    unsigned const bpp = (a.seg_nq + 3u) / 4u; // blocks per profile: four queries each
+    unsigned const seg = a.seg_index;          // this launch's segment
+    float const ni = neg_inf();
+    // (a do-while(false): `continue` leaves the block's one task)
+    for (unsigned once = 0; once < 1u && vblk < a.nprof * bpp; ++once)
     {
-        unsigned const task = xcd * per_x + ti;
-        if (task >= ntasks) break;
-        unsigned const s_rel = task / a.seg_nq;
+        unsigned const s_rel = vblk / bpp;
         unsigned const slot = __builtin_amdgcn_readfirstlane(a.first_prof + s_rel);
-        unsigned const q = __builtin_amdgcn_readfirstlane(a.seg_q0 + (task - s_rel * a.seg_nq));
+        unsigned const qi = (vblk - s_rel * bpp) * 4u + wave; // this wavefront's query of the chunk
+        bool const has_q = qi < a.seg_nq;                      // a spare wavefront only helps with the copy
+        unsigned const q = __builtin_amdgcn_readfirstlane(a.seg_q0 + (has_q ? qi : 0u));
+        unsigned const task = s_rel * a.seg_nq + qi;           // the pair's column
         dcp_prof_meta const pm = a.profs[slot];
         unsigned const ldk = pm.ldk; // core_size + 8 rounded up to 4, at most the class capacity
         unsigned const nseg = (pm.core_size + 64u * R - 1u) / (64u * R);
-        if (seg >= nseg) continue; // a shorter profile of the class: done in an earlier launch
+        if (seg >= nseg) continue; // a shorter profile of the class: done in an earlier launch (block-uniform)
         bool const last = seg + 1u == nseg;
         bool const flagged = (pm.flags & DCP_PROF_EXACT_E) != 0u;
         if (flagged)
         {
             // E(j) is not the match states' maximum for this profile: the exact kernel scores all its pairs
-            if (last && lane == 0u)
+            if (last && has_q && lane == 0u)
             {
                 unsigned const h = atomicAdd(a.seg_redo_n, 1u);
                 if (h < a.seg_redo_cap) a.seg_redo[h] = dcp_pair{q, slot};
@@ -944,6 +955,20 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp
             continue;
         }
         float const *__restrict__ em_prof = a.emis_match + pm.emis_off;
+        unsigned const col0 = seg * 64u * R; // the segment's first column
+        {
+            // the segment's columns of the table's first kSegStaged rows: [code][SLD] in LDS
+            unsigned const ncols = min(ldk - col0, SLD); // multiple of 4 (ldk and col0 are)
+            unsigned const n4 = ncols >> 2;
+            for (unsigned i = threadIdx.x; i < (unsigned)kSegStaged * n4; i += 256u)
+            {
+                unsigned const c = i / n4, k = i - c * n4;
+                reinterpret_cast<float4 *>(stage_mem + c * SLD)[k] =
+                    reinterpret_cast<float4 const *>(em_prof + (size_t)c * ldk + col0)[k];
+            }
+            __syncthreads();
+        }
+        if (!has_q) continue;
         cfloat *eN_tab = as_const(a.emis_null + (size_t)pm.pidx * DCP_NCODES);
         cfloat *eI_tab = as_const(a.emis_insert + (size_t)pm.pidx * DCP_NCODES);
         unsigned const L = a.seq_len[q];
@@ -958,8 +983,12 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp
         float xEB = xt[DCP_X_EB];
         asm volatile("" : "+v"(xEB));
         RowOut o{ni, ni};
-        unsigned const node0 = seg * 64u * R + lane * R;
-        unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the -inf tail
+        unsigned const node0 = col0 + lane * R;
+        // a lane past the last node reads R columns of the row's -inf tail: the first aligned ones, which the staged
+        // image holds too (at most kSegStagePad past the segment's columns); a row clipped to the class capacity
+        // (no full tail) ends in them
+        unsigned const m4 = (pm.core_size + 3u) & ~3u;
+        unsigned const lane_off = node0 < pm.core_size ? node0 : (m4 + R <= ldk ? m4 : ldk - R);
         float const *__restrict__ em_base = em_prof; // wave-uniform; the lane's columns through lane_boff
         Trans<R> t;
         {
@@ -999,7 +1028,9 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp
         float em[5][R], eN[5], eI[5];
         unsigned w = base_at(words, 0);
         unsigned lane_boff = lane_off * 4u;
-        load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr);
+        // the staged image starts at the segment's first column: the same lane offset minus col0 (as a pointer bias)
+        float const *const stg = stage_mem - col0;
+        load_row<R, kSegStaged>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg, SLD);
         SegBnd bnd{ni, ni, ni, ni}, bnx{ni, ni, ni, ni};
         if (seg > 0u) bnd = SegBnd{bsrc[4], bsrc[5], bsrc[6], bsrc[7]}; // row 1
         unsigned j = 1;
@@ -1008,7 +1039,7 @@ __global__ __launch_bounds__(256, DCP_SEG_WAVES) void viterbi_segment_kernel(dcp
     {                                                                                             \
         w = ((w << 2) | base_at(words, j)) & 1023u;                                               \
         o = seg_row<R, PH, LASTSEG>(s, t, em, eN, eI, sp, cJ, xEB, bnd, bdst + j, lane, seg_dirty, [&]() { \
-            load_row<R, 0>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, nullptr); \
+            load_row<R, kSegStaged>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg, SLD); \
             if (seg > 0u) /* row L + 1 exists (never written: garbage, unused) */                  \
                 bnx = SegBnd{bsrc[4u * j + 4u], bsrc[4u * j + 5u], bsrc[4u * j + 6u], bsrc[4u * j + 7u]}; \
         });                                                                                       \
@@ -1654,7 +1685,8 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
     return dcp_launch_rowsweep(R, W, a, nblocks, stream);
 }
 
-extern "C" unsigned dcp_segsweep_blocks_per_cu(void) { return DCP_SEG_WAVES; } // four-wavefront blocks: its waves per SIMD
+// blocks of a segment launch: four queries of one profile each, rounded up to the XCD count
+extern "C" unsigned dcp_segsweep_blocks(unsigned nprof, unsigned nq) { return (nprof * ((nq + 3u) / 4u) + 7u) / 8u * 8u; }
 // nodes per lane of a segment of the (R, W) multi-wavefront class: 6 (384-node segments) for the R = 3 classes, 8
 // (512-node segments) for the R = 4 ones -- the classes' capacities are multiples of those; 0: no segmented kernel
 extern "C" int dcp_segsweep_nodes_per_lane(int R, int W) { return W > 1 ? (R == 3 ? 6 : R == 4 ? 8 : 0) : 0; }

@@ -313,11 +313,17 @@ __device__ __forceinline__ unsigned ring_wait(LdsLink const &lk, unsigned need)
         v = __builtin_amdgcn_readfirstlane(flag_load(flag));
         if (__builtin_expect(++spins == kRingSpinBound, 0))
         {
-            unsigned *const err = *(unsigned *__attribute__((address_space(3))) *)(lk.base + kL2Err);
+            typedef unsigned __attribute__((address_space(1))) *gerr_ptr;
+            gerr_ptr const err = *(gerr_ptr __attribute__((address_space(3))) *)(lk.base + kL2Err);
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag_store((lds_uint *)(lk.base + kL2Abort), 1u); // this block's task winds down at its next step
             flag_store(flag, kRingPoison);
             v = kRingPoison;
+            // Nothing of this block may be pending where it joins the row loop again: the compiler's waitcnt pass
+            // merges the two paths' counters, and with this path's LDS stores outstanding the row's first counted
+            // wait -- lgkmcnt(5), which lets the five group-1 gathers just issued fly -- became lgkmcnt(0): 1 % of
+            // the C3 launch for a block that never runs (profiles/r04/ring_bound_ab.txt).
+            __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) lgkmcnt(0)
         }
     }
 #else
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
     lk.my_flag = stage == 0u ? kL2FlagP : kL2FlagC;
     lk.peer_flag = (stage == 0u ? kL2FlagC : kL2FlagP) + (tid & ~63u) * 4u;
     lk.seen = 0u;
-    if (threadIdx.x == 0) *(unsigned **)(lds + kL2Err / 4u) = a.ring_error;
+    if (threadIdx.x == 0) *(unsigned **)(lds + kL2Err / 4u) = a.ring_error; // (a global address: ring_wait reads it back as one)
     unsigned *const s_abort_p = reinterpret_cast<unsigned *>(lds + kL2Abort / 4u);
 
     for (;;)
