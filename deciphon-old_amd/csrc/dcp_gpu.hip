@@ -41,7 +41,7 @@ constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}
 // cells/s of each class on a full grid, measured on the C3 DB (profiles/r03/rowsweep_variants.txt; round 2:
 // profiles/r02/rowsweep_tuning.txt): the kernel choice prices a row-sweep scan with them
 constexpr double kClassRate[] = {600e9, 930e9, 1120e9, 1250e9, 1240e9, 1320e9, 1220e9, 1230e9,
-                                 680e9, 650e9, 750e9, 560e9, 600e9, 400e9}; // R = 3 multi-wavefront classes: the segmented sweep
+                                 830e9, 960e9, 820e9, 600e9, 600e9, 600e9}; // multi-wavefront classes: the segmented sweep (round 4: profiles/r04/rowsweep_multiwave.txt)
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
 static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
 static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
@@ -51,6 +51,17 @@ int class_of(unsigned M)
     for (int c = 0; c < kNumClasses; ++c)
         if (M <= kClasses[c].cap()) return c;
     return -1;
+}
+
+// Nodes per lane of the segments a profile of more than 512 nodes is cut into by the segmented row sweep
+// (viterbi_segment_kernel): the fewest segments of at most 512 nodes, and the narrowest lanes that cover the profile
+// with them -- R = ceil(M / (64 x ceil(M / 512))), 5..8 -- so that a segment's lanes are at least 80 % full (with a
+// fixed 384 / 512 nodes per class they were 67 .. 100 %).  0: a one-wavefront profile.
+unsigned seg_r_of(unsigned M)
+{
+    if (M <= 512u) return 0u;
+    unsigned const nseg = (M + 511u) / 512u;
+    return (M + 64u * nseg - 1u) / (64u * nseg);
 }
 
 template <class T> struct DevBuf
@@ -370,8 +381,12 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     std::vector<unsigned> order(nprofiles);
     for (unsigned p = 0; p < nprofiles; ++p)
         order[p] = p;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](unsigned a, unsigned b) { return cls[a] < cls[b]; });
+    // by size class; inside a class of several wavefronts by the segmented sweep's lane width (seg_r_of), so that the
+    // profiles of one segment kernel are a contiguous range; then by the caller's index
+    std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
+        if (cls[a] != cls[b]) return cls[a] < cls[b];
+        return seg_r_of(c->core_sizes[a]) < seg_r_of(c->core_sizes[b]);
+    });
 
     c->metas.assign(nprofiles, dcp_prof_meta{});
     std::vector<uint32_t> dist_row(nprofiles);
@@ -1373,10 +1388,12 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         unsigned const np = c->class_first[k + 1] - c->class_first[k];
         SizeClass const sc = kClasses[k];
         uint64_t const pairs = (uint64_t)np * nq;
-        // (from about 32 queries on: below, a pair's segments one after the other are a longer serial chain than the
-        // exact kernel's wavefronts side by side -- 1 query 11.8 -> 14.4 ms, 16 queries 79 -> 81, 64: 252 -> 247)
-        bool const want = c->seg_mode == 1 || (c->seg_mode < 0 && nq >= 32u);
-        bool const have = dcp_segsweep_nodes_per_lane(sc.R, sc.W) != 0 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
+        // (once the class has pairs enough to fill the chip's wavefront slots twice over: below, a pair's segments one
+        // after the other are a longer serial chain than the exact kernel's wavefronts side by side -- C3 DB, 1 query
+        // 11.8 -> 14.4 ms with round 3's kernel; C5 DB, where 37 % of the profiles are in these classes: 16 queries
+        // 291 ms with the exact kernel, profiles/r04/latency_probe_c5_db.txt)
+        bool const want = c->seg_mode == 1 || (c->seg_mode < 0 && pairs >= 16ull * c->num_cus);
+        bool const have = sc.W > 1 && want && np > 0 && pairs <= ((uint64_t)1 << 26);
         if (!have) continue;
         // queries per chunk: np x chunk pairs x 2 columns x seg_stride x 16 bytes within the cap
         uint64_t const per_query = (uint64_t)np * 2u * seg_stride * 16u;
@@ -1414,26 +1431,37 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         if (seg_blocks[k])
         {
             unsigned const np = a.nprof, chunk = seg_chunk[k];
-            int const segR = dcp_segsweep_nodes_per_lane(sc.R, sc.W);
-            unsigned const nseg_max = (sc.cap() + 64u * (unsigned)segR - 1u) / (64u * (unsigned)segR);
-            a.seg_col0 = c->d_seg_scratch.p + seg_col_at;
-            a.seg_col1 = a.seg_col0 + (size_t)np * chunk * seg_stride * 4u;
+            float *const col_base = c->d_seg_scratch.p + seg_col_at;
             seg_col_at += (uint64_t)np * chunk * 2u * seg_stride * 4u;
             a.seg_stride = seg_stride;
             a.seg_redo = c->d_seg_redo.p + seg_redo_off[k];
             a.seg_redo_n = c->d_seg_redo_n.p + k;
             a.seg_redo_cap = (unsigned)ntasks;
-            // segment-major: launch s sweeps segment s of every pair of the chunk; the kernel boundary is the hand-off
-            for (unsigned qc = 0; qc < nq; qc += chunk)
+            // Segment-major: launch s sweeps segment s of every pair of the chunk; the kernel boundary is the hand-off.
+            // The class's profiles are ordered by their segments' lane width: one run of launches per width.
+            for (unsigned sub = first; sub < last;)
             {
-                a.seg_q0 = qc, a.seg_nq = std::min(chunk, nq - qc);
-                for (unsigned sg = 0; sg < nseg_max; ++sg)
+                unsigned const segR = seg_r_of(c->metas[sub].core_size);
+                unsigned sub_end = sub, max_m = 0;
+                while (sub_end < last && seg_r_of(c->metas[sub_end].core_size) == segR)
+                    max_m = std::max(max_m, c->metas[sub_end].core_size), ++sub_end;
+                unsigned const nsub = sub_end - sub, nseg_max = (max_m + 64u * segR - 1u) / (64u * segR);
+                a.first_prof = sub, a.nprof = nsub;
+                a.seg_col0 = col_base + (size_t)(sub - first) * chunk * 2u * seg_stride * 4u;
+                a.seg_col1 = a.seg_col0 + (size_t)nsub * chunk * seg_stride * 4u;
+                for (unsigned qc = 0; qc < nq; qc += chunk)
                 {
-                    a.seg_index = sg;
-                    if (dcp_launch_segsweep(sc.R, sc.W, &a, dcp_segsweep_blocks(np, a.seg_nq), ls))
-                        return c->fail(DCP_EFAIL, "no segmented kernel for class R=%d W=%d", sc.R, sc.W);
+                    a.seg_q0 = qc, a.seg_nq = std::min(chunk, nq - qc);
+                    for (unsigned sg = 0; sg < nseg_max; ++sg)
+                    {
+                        a.seg_index = sg;
+                        if (dcp_launch_segsweep((int)segR, &a, dcp_segsweep_blocks(nsub, a.seg_nq), ls))
+                            return c->fail(DCP_EFAIL, "no segmented kernel for %u nodes per lane", segR);
+                    }
                 }
+                sub = sub_end;
             }
+            a.first_prof = first, a.nprof = np;
             HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
             c->launched_redo[c->n_launched] = false;
             c->launched_class[c->n_launched++] = k;

@@ -199,9 +199,9 @@ void dcp_launch_expand(dcp_expand_args const *a, unsigned ntiles, void *stream);
 int dcp_launch_rowsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks,
                         void *stream);
 unsigned dcp_rowsweep_tasks_per_block(int W);
-// segment a->seg_index of every pair of a multi-wavefront class, one wavefront per pair; != 0: no such kernel
-int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
-int dcp_segsweep_nodes_per_lane(int R, int W); // nodes per lane of that class's segments (0: none)
+// segment a->seg_index of every pair of the launch's profiles x queries, one wavefront per pair, segments of 64 x R
+// nodes (R = 5..8); != 0: no such kernel
+int dcp_launch_segsweep(int R, dcp_scan_args const *a, unsigned nblocks, void *stream);
 unsigned dcp_segsweep_blocks(unsigned nprof, unsigned nq); // grid of one segment launch over nprof profiles x nq queries
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large

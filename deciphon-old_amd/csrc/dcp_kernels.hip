@@ -906,17 +906,17 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
 // Like the one-wavefront classes' large-batch kernels, a block is four wavefronts scoring consecutive queries
 // against ONE profile's segment, whose 20 leading emission rows (the one- and two-base words: two of a row's five
 // reads) they copy to LDS together -- the segment's 64 x R columns plus the few of the row's -inf tail a lane past
-// the last node points at.  R = 6 runs three wavefronts per SIMD (168 VGPRs) like R6W1's large-batch variant.
-#ifndef DCP_SEG_WAVES6
-#define DCP_SEG_WAVES6 3
+// the last node points at.  Two wavefronts per SIMD (no spills in the row loops).
+#ifndef DCP_SEG_WAVES5
+#define DCP_SEG_WAVES5 3 // R = 5 (profiles of 513 .. 640 nodes)
 #endif
-#ifndef DCP_SEG_WAVES8
-#define DCP_SEG_WAVES8 2
+#ifndef DCP_SEG_WAVES
+#define DCP_SEG_WAVES 2 // R = 6 at three (168 VGPRs, 82 spilled, 34 scratch operations per five rows of the last segment's loop): R3W4 266 ms against 256
 #endif
 constexpr int kSegStaged = 20;      // rows of the segment's image in LDS
 constexpr unsigned kSegStagePad = 8; // columns past the segment's 64 x R that a staged row also holds
 template <int R>
-__global__ __launch_bounds__(256, R == 6 ? DCP_SEG_WAVES6 : DCP_SEG_WAVES8) void viterbi_segment_kernel(dcp_scan_args a)
+__global__ __launch_bounds__(256, R == 5 ? DCP_SEG_WAVES5 : DCP_SEG_WAVES) void viterbi_segment_kernel(dcp_scan_args a)
 {
     constexpr unsigned SLD = 64u * R + kSegStagePad; // floats per staged row
     __shared__ __attribute__((aligned(16))) float stage_mem[kSegStaged * SLD];
@@ -1687,19 +1687,20 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
 
 // blocks of a segment launch: four queries of one profile each, rounded up to the XCD count
 extern "C" unsigned dcp_segsweep_blocks(unsigned nprof, unsigned nq) { return (nprof * ((nq + 3u) / 4u) + 7u) / 8u * 8u; }
-// nodes per lane of a segment of the (R, W) multi-wavefront class: 6 (384-node segments) for the R = 3 classes, 8
-// (512-node segments) for the R = 4 ones -- the classes' capacities are multiples of those; 0: no segmented kernel
-extern "C" int dcp_segsweep_nodes_per_lane(int R, int W) { return W > 1 ? (R == 3 ? 6 : R == 4 ? 8 : 0) : 0; }
-
-// One launch = segment a->seg_index of every (profile, query) pair of a multi-wavefront class (viterbi_segment_kernel);
-// != 0 if there is no such kernel.  a->seg_col0 / seg_col1: the pairs' boundary columns, a->seg_stride float4 each.
-extern "C" int dcp_launch_segsweep(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream)
+// One launch = segment a->seg_index of every (profile, query) pair of a->first_prof .. + a->nprof, profiles cut into
+// segments of 64 x R nodes (viterbi_segment_kernel<R>, R = 5..8); != 0 if there is no such kernel.
+// a->seg_col0 / seg_col1: the pairs' boundary columns, a->seg_stride rows of 16 bytes each.
+extern "C" int dcp_launch_segsweep(int R, dcp_scan_args const *a, unsigned nblocks, void *stream)
 {
-    int const r = dcp_segsweep_nodes_per_lane(R, W);
-    if (r == 6) hipLaunchKernelGGL((viterbi_segment_kernel<6>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
-    else if (r == 8) hipLaunchKernelGGL((viterbi_segment_kernel<8>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a);
-    else return -1;
-    return 0;
+#define DCP_CASE_G(r)                                                                                          \
+    if (R == r)                                                                                                \
+    {                                                                                                          \
+        hipLaunchKernelGGL((viterbi_segment_kernel<r>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, *a); \
+        return 0;                                                                                              \
+    }
+    DCP_CASE_G(5) DCP_CASE_G(6) DCP_CASE_G(7) DCP_CASE_G(8)
+#undef DCP_CASE_G
+    return -1;
 }
 
 // unstaged kernels: pair mode (a->pairs), the classes of several wavefronts per pair, and grid mode without staging

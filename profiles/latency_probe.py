@@ -1,10 +1,14 @@
-"""Small-batch scan latency on the C3 DB (the reference scans one sequence at a time: scan.c:227-258)."""
+"""Small-batch scan latency on the C3 DB -- or, `python3 profiles/latency_probe.py c5`, on the C5 DB (20 000 profiles of
+50 .. 2 000 nodes: 37 % of them in the multi-wavefront classes) -- with 1 kbp queries (the reference scans one sequence
+at a time: scan.c:227-258)."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 dcp = bench.load_product()
-sizes = bench.core_sizes_for("c3", 20000)
+WL = sys.argv[1] if len(sys.argv) > 1 else "c3"
+sizes = bench.core_sizes_for(WL, 20000)
+print(f"workload {WL}: 20000 profiles, sum M = {int(sizes.sum())}", flush=True)
 cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
 from concurrent.futures import ThreadPoolExecutor
 with ThreadPoolExecutor(16) as ex:
@@ -20,6 +24,8 @@ for kname, kern in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP)
                     ("qlane2", dcp.KERNEL_QLANE2)):
     for nq in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 256, 512, 1024):
         if kname == "rowsweep" and nq > 64 or kname.startswith("qlane") and nq < 16:
+            continue
+        if WL != "c3" and (nq > 256 or nq in (2, 4, 48, 96) or kname == "qlane"):
             continue
         for rep in range(2):
             t = time.perf_counter()

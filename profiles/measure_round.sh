@@ -3,9 +3,10 @@
 # judged into profiles/rNN/).  Two parts so that each fits one gpurun call:
 #   gpurun --timeout 1100 -- 'bash profiles/measure_round.sh r02m driver'
 #   gpurun --timeout 1100 -- 'bash profiles/measure_round.sh r02m lines'
+#   gpurun --timeout 1100 -- 'bash profiles/measure_round.sh r04m pmc'
 #   gpurun --timeout 1190 -- 'bash profiles/measure_round.sh r03m c5full'
 set -o pipefail
-TAG=${1:?tag}; PART=${2:?driver|lines|c5full}
+TAG=${1:?tag}; PART=${2:?driver|lines|pmc|c5full}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 line() { # name, bench args...
   local name=$1; shift
@@ -29,6 +30,13 @@ lines)
   DCP_BENCH_FORCE_DIST=1 line c3_bench_c_rccl_gather_1rank --steps 3 --warmup 1 --no-cpu-baseline
   timeout -k 10 400 python3 profiles/latency_probe.py > $OUT/latency_probe.txt 2>&1; grep "^auto" $OUT/latency_probe.txt
   timeout -k 10 300 python3 profiles/smalldb_probe.py > $OUT/smalldb_probe.txt 2>&1; tail -3 $OUT/smalldb_probe.txt
+  ;;
+pmc)
+  # the headline's literal 10 000-query batch, the HBM counter passes of the driver's workload
+  # (FETCH_SIZE / WRITE_SIZE in separate runs; folded by pmc_summary.py), and the row sweep's per-class counters
+  line c3_bench_10000q --qstep 10000 --steps 2 --warmup 1 --no-cpu-baseline --e2e-steps 0
+  PASSES="fetch write" PASS_TIMEOUT=300 bash profiles/collect_pmc.sh $TAG/pmc_qlane2 --steps 5 --warmup 1 --no-cpu-baseline --e2e-steps 0
+  timeout -k 10 400 python3 profiles/latency_probe.py c5 > $OUT/latency_probe_c5_db.txt 2>&1; grep "^auto" $OUT/latency_probe_c5_db.txt
   ;;
 c5full)
   # BASELINE configs[4] at full size on one GPU: all 20 000 profiles (M 50-2000) x one step of 8 192 mixed-length
