@@ -46,6 +46,10 @@ constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
 static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
 static_assert(kNumClasses <= DCP_MAX_CLASSES, "redo lists are sized for DCP_MAX_CLASSES size classes");
 
+// profiles per wavefront of the two smallest classes in grid mode (viterbi_mp_kernel<K>: 64 / K lanes x 4 nodes each)
+constexpr unsigned kMpParts[2] = {4u, 2u};
+constexpr unsigned kMpClass1MaxQueries = 96u; // the 65 .. 128-node class runs two profiles per wavefront below this many queries
+
 int class_of(unsigned M)
 {
     for (int c = 0; c < kNumClasses; ++c)
@@ -120,6 +124,13 @@ struct dcp_gpu_ctx
     DevBuf<float> d_emis_tiles, d_ttrans, d_scratch;
     DevBuf<uint32_t> d_qorder;
     DevBuf<uint32_t> d_words_t, d_wt_off; // query-lane kernel: per-block window planes
+    // profiles of at most 128 nodes: groups of K sharing table rows (dcp_mp_group), per row-sweep class 0 / 1
+    std::vector<dcp_mp_group> mp_groups;
+    unsigned mp_first[3] = {0, 0, 0};        // groups of class 0: [mp_first[0], mp_first[1]), class 1: [mp_first[1], mp_first[2])
+    unsigned mp_flagged_first[2] = {0, 0};   // first flagged (ungrouped) profile of class 0 / 1 in metas order
+    DevBuf<dcp_mp_group> d_mp_groups;
+    DevBuf<float> d_mp_in;                   // [group][1364][K] {eI, eN}
+    bool mp_in_ready = false;
     DevBuf<dcp_ql_group> d_ql_groups;     // groups of up to 64 queries and the wavefront slots they are packed into
     DevBuf<uint32_t> d_slot_first;
     unsigned ql_nqb = 0, ql_plane_rows = 0; // the cached plan: blocks of slots, rows of a block's scratch planes
@@ -188,6 +199,7 @@ struct dcp_gpu_ctx
     DevBuf<dcp_pair> d_seg_redo;
     DevBuf<unsigned> d_seg_redo_n; // [DCP_MAX_CLASSES]
     int seg_mode = -1;             // test hook: 0 never, 1 always where a kernel exists, -1 automatic
+    int mp_mode = -1;              // test hook: 0 never K profiles per wavefront, 1 always, -1 automatic
     uint64_t seg_col_bytes = (uint64_t)6 << 30; // cap on one class's boundary columns (test hook: shrink it to reach the chunked path)
     unsigned n_launched = 0;
 
@@ -378,13 +390,28 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         cls[p] = k;
         c->core_sizes[p] = M;
     }
+    // E(j) as the match states' maximum (both kernels) needs MD, DD <= 0: true of every profile whose
+    // transitions are log-probabilities.  Any other profile is flagged: the row sweep then takes the
+    // delete states into E(j), the query-lane kernels hand its pairs to the row sweep (redo lists).
+    std::vector<uint8_t> flagged(nprofiles, 0);
+    for (unsigned p = 0; p < nprofiles; ++p)
+    {
+        float const *t8 = dcp_profile_trans8(profiles[p]);
+        unsigned const M = c->core_sizes[p];
+        bool pos = false;
+        for (unsigned k = 1; k < M && !pos; ++k) // edges into node 0 do not exist (-inf below)
+            pos = t8[(size_t)DCP_T_MD * M + k] > 0.0f || t8[(size_t)DCP_T_DD * M + k] > 0.0f;
+        flagged[p] = pos ? 1 : 0;
+    }
     std::vector<unsigned> order(nprofiles);
     for (unsigned p = 0; p < nprofiles; ++p)
         order[p] = p;
     // by size class; inside a class of several wavefronts by the segmented sweep's lane width (seg_r_of), so that the
-    // profiles of one segment kernel are a contiguous range; then by the caller's index
+    // profiles of one segment kernel are a contiguous range; inside the two smallest classes the flagged profiles last
+    // (the others are grouped K to a wavefront: kMpParts); then by the caller's index
     std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
         if (cls[a] != cls[b]) return cls[a] < cls[b];
+        if (cls[a] < 2) return flagged[a] < flagged[b];
         return seg_r_of(c->core_sizes[a]) < seg_r_of(c->core_sizes[b]);
     });
 
@@ -393,41 +420,86 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     uint64_t emis_floats = 0, trans_floats = 0, match_rows = 0;
     for (int k = 0; k <= kNumClasses; ++k)
         c->class_first[k] = 0;
-    for (unsigned i = 0; i < nprofiles; ++i)
+    c->mp_groups.clear();
+    c->mp_first[0] = c->mp_first[1] = c->mp_first[2] = 0;
+    c->mp_flagged_first[0] = c->mp_flagged_first[1] = 0;
+    c->mp_in_ready = false;
+    uint64_t mp_in_pairs = 0;
+    for (unsigned i = 0; i < nprofiles;)
     {
-        unsigned p = order[i];
-        // Row length of the profile's tables.  Several wavefronts per pair: the class capacity (every lane has
-        // columns, the padding ones -inf).  One wavefront: core_size + R columns rounded up to 4 -- every row
-        // ends in at least R columns of -inf, which all lanes past the last node read (the row-sweep kernel
-        // points them there) instead of owning padding columns: 15 % fewer bytes per row on a Pfam-like
-        // size distribution (24 -> 20.6 GB for the 20 000-profile DB), fewer HBM and L2 lines per DP row.
-        SizeClass const sc = kClasses[cls[p]];
-        unsigned ldk = sc.cap();
-        if (sc.W == 1 && c->core_sizes[p] <= 63u * (unsigned)sc.R) ldk = (c->core_sizes[p] + (unsigned)sc.R + 3u) & ~3u;
-        // several wavefronts per pair: the same, with room for the segmented sweep's 6-node lanes in the tail
-        if (sc.W > 1) ldk = std::min(ldk, (c->core_sizes[p] + 8u + 3u) & ~3u); // (rows rounded up to 128 bytes instead: no difference, measured)
-        dcp_prof_meta &m = c->metas[i];
-        m.emis_off = emis_floats;
-        m.trans_off = (uint32_t)trans_floats;
-        m.core_size = c->core_sizes[p];
-        m.ldk = ldk;
-        m.pidx = p;
+        unsigned const p0 = order[i];
+        int const k0 = cls[p0];
+        SizeClass const sc = kClasses[k0];
+        // The two smallest classes (at most 128 nodes), unflagged: kMpParts[class] consecutive profiles share one
+        // table -- their columns side by side, each followed by >= 8 columns of -inf -- and one wavefront scores
+        // them against a query together (viterbi_mp_kernel).  Each member's meta is a column view of that table.
+        unsigned members = 1;
+        if (k0 < 2 && !flagged[p0])
+            while (members < kMpParts[k0] && i + members < nprofiles && cls[order[i + members]] == k0 && !flagged[order[i + members]])
+                ++members;
+        bool const grouped = k0 < 2 && !flagged[p0];
+        unsigned widths[4] = {0, 0, 0, 0}, ldk = 0;
+        for (unsigned j = 0; j < members; ++j)
         {
-            // E(j) as the match states' maximum (both kernels) needs MD, DD <= 0: true of every profile whose
-            // transitions are log-probabilities.  Any other profile is flagged: the row sweep then takes the
-            // delete states into E(j), the query-lane kernels hand its pairs to the row sweep (redo lists).
-            float const *t8 = dcp_profile_trans8(profiles[p]);
-            bool pos = false;
-            for (unsigned k = 1; k < m.core_size && !pos; ++k) // edges into node 0 do not exist (-inf below)
-                pos = t8[(size_t)DCP_T_MD * m.core_size + k] > 0.0f || t8[(size_t)DCP_T_DD * m.core_size + k] > 0.0f;
-            m.flags = pos ? DCP_PROF_EXACT_E : 0u;
+            unsigned const M = c->core_sizes[order[i + j]];
+            if (grouped) widths[j] = (M + 8u + 3u) & ~3u;
+            else
+            {
+                // Row length of a stand-alone profile's tables.  Several wavefronts per pair: the class capacity
+                // (every lane has columns, the padding ones -inf), or core_size + 8 if that is shorter.  One
+                // wavefront: core_size + R columns rounded up to 4 -- every row ends in at least R columns of -inf,
+                // which all lanes past the last node read instead of owning padding columns: 15 % fewer bytes per
+                // row on a Pfam-like size distribution, fewer HBM and L2 lines per DP row.
+                unsigned w = sc.cap();
+                if (sc.W == 1 && M <= 63u * (unsigned)sc.R) w = (M + (unsigned)sc.R + 3u) & ~3u;
+                if (sc.W > 1) w = std::min(w, (M + 8u + 3u) & ~3u);
+                widths[j] = w;
+            }
+            ldk += widths[j];
         }
-        dist_row[i] = (uint32_t)match_rows;
+        dcp_mp_group g{};
+        if (grouped)
+        {
+            g.emis_off = emis_floats, g.trans_off = (uint32_t)trans_floats, g.ldk = ldk;
+            g.in_off = (uint32_t)mp_in_pairs, g.nparts = members;
+            mp_in_pairs += (uint64_t)DCP_NCODES * kMpParts[k0];
+        }
+        unsigned col0 = 0;
+        for (unsigned j = 0; j < members; ++j)
+        {
+            unsigned const p = order[i + j];
+            dcp_prof_meta &m = c->metas[i + j];
+            m.emis_off = emis_floats + col0;
+            m.trans_off = (uint32_t)(trans_floats + col0);
+            m.core_size = c->core_sizes[p];
+            m.ldk = ldk;
+            m.width = widths[j];
+            m.pidx = p;
+            m.flags = flagged[p] ? DCP_PROF_EXACT_E : 0u;
+            dist_row[i + j] = (uint32_t)match_rows;
+            match_rows += m.core_size;
+            if (grouped) g.col0[j] = col0, g.core_size[j] = m.core_size, g.pidx[j] = p, g.slot[j] = i + j;
+            col0 += widths[j];
+        }
+        if (grouped)
+        {
+            // an absent member's lanes read -inf: the padding behind the last member
+            for (unsigned j = members; j < 4; ++j)
+                g.col0[j] = g.col0[members - 1] + ((g.core_size[members - 1] + 3u) & ~3u), g.core_size[j] = 0;
+            c->mp_groups.push_back(g);
+            c->mp_first[k0 + 1] = (unsigned)c->mp_groups.size();
+        }
+        else if (k0 < 2 && c->mp_flagged_first[k0] == 0 && flagged[p0])
+            c->mp_flagged_first[k0] = i + 1u; // (+1: 0 means none)
         emis_floats += (uint64_t)DCP_NCODES * ldk;
         trans_floats += 8ull * ldk;
-        match_rows += m.core_size;
-        c->class_first[cls[p] + 1] = i + 1;
+        for (unsigned j = 0; j < members; ++j)
+            c->class_first[cls[order[i + j]] + 1] = i + j + 1;
+        i += members;
     }
+    if (c->mp_first[1] < c->mp_first[0]) c->mp_first[1] = c->mp_first[0];
+    if (c->mp_first[2] < c->mp_first[1]) c->mp_first[2] = c->mp_first[1];
+    if (mp_in_pairs > 0xffffffffull) return c->fail(DCP_EINVAL, "DB too large for 32-bit table offsets");
     for (int k = 1; k <= kNumClasses; ++k) // empty classes inherit the boundary
         if (c->class_first[k] < c->class_first[k - 1]) c->class_first[k] = c->class_first[k - 1];
     if (trans_floats > 0xffffffffull || match_rows > 0xffffffffull)
@@ -462,7 +534,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             float const *src = dcp_profile_trans8(profiles[m.pidx]);
             for (int row = 0; row < 8; ++row)
                 std::memcpy(&t8[m.trans_off + (size_t)row * m.ldk], src + (size_t)row * m.core_size,
-                            sizeof(float) * m.core_size);
+                            sizeof(float) * m.core_size); // (a view: row stride = the group's ldk)
             // The first node has no predecessor node: whatever a caller-built profile (dcp_profile_from_parts)
             // holds there, the edges into it are -inf.  The row sweep relies on it (lane 0 adds them to 0).
             for (int row : {DCP_T_MM, DCP_T_IM, DCP_T_DM, DCP_T_MD, DCP_T_DD})
@@ -535,12 +607,13 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         std::vector<float> col(DCP_NCODES), tab;
         std::vector<float> ins((size_t)nprofiles * DCP_NCODES), nul((size_t)nprofiles * DCP_NCODES);
         float const ninf = -std::numeric_limits<float>::infinity();
+        std::vector<float> emis_host((size_t)emis_floats, ninf);
         for (unsigned i = 0; i < nprofiles; ++i)
         {
             dcp_prof_meta const &m = c->metas[i];
             dcp_profile const *pr = profiles[m.pidx];
             float eps = dcp_profile_epsilon(pr);
-            tab.assign((size_t)DCP_NCODES * m.ldk, ninf);
+            tab.assign((size_t)DCP_NCODES * m.width, ninf);
             dcp_ql_prof const &qm = c->ql_metas[i];
             std::vector<float> img((size_t)qm.ntiles * KT * DCP_NCODES, ninf);
             float const *md = dcp_profile_match_dist(pr);
@@ -550,17 +623,20 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
                 size_t const grp = (size_t)(k / KT) * (KT / 4) + (k % KT) / 4;
                 for (unsigned code = 0; code < DCP_NCODES; ++code)
                 {
-                    tab[(size_t)code * m.ldk + k] = col[code];
+                    tab[(size_t)code * m.width + k] = col[code];
                     img[(grp * DCP_NCODES + code) * 4 + (k & 3u)] = col[code];
                 }
             }
-            HIP_TRY(c, hipMemcpy(c->d_emis_match.p + m.emis_off, tab.data(), tab.size() * sizeof(float),
-                                 hipMemcpyHostToDevice));
+            // its own columns of rows it may share with other profiles: into the host image of all tables, which goes
+            // to the device in one piece below (this path is the tests': small databases)
+            for (unsigned code = 0; code < DCP_NCODES; ++code)
+                std::memcpy(&emis_host[m.emis_off + (size_t)code * m.ldk], &tab[(size_t)code * m.width], sizeof(float) * m.width);
             HIP_TRY(c, hipMemcpy(c->d_emis_tiles.p + qm.tile_off, img.data(), img.size() * sizeof(float),
                                  hipMemcpyHostToDevice));
             dcp_frame_table_host(dcp_profile_insert_dist(pr), eps, &ins[(size_t)m.pidx * DCP_NCODES]);
             dcp_frame_table_host(dcp_profile_null_dist(pr), eps, &nul[(size_t)m.pidx * DCP_NCODES]);
         }
+        HIP_TRY(c, hipMemcpy(c->d_emis_match.p, emis_host.data(), emis_host.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_emis_insert.p, ins.data(), ins.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_emis_null.p, nul.data(), nul.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -597,13 +673,13 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         for (unsigned i = 0; i < nprofiles; ++i)
         {
             dcp_prof_meta const &m = c->metas[i];
-            for (unsigned k0 = 0; k0 < m.ldk; k0 += 64)
+            for (unsigned k0 = 0; k0 < m.width; k0 += 64) // its own columns of the (possibly shared) rows
             {
                 dcp_expand_tile t{};
                 t.out_off = m.emis_off + k0;
                 t.ncols = k0 < m.core_size ? std::min(64u, m.core_size - k0) : 0u;
                 t.dist_row = t.ncols ? dist_row[i] + k0 : 0u;
-                t.nstore = std::min(64u, m.ldk - k0);
+                t.nstore = std::min(64u, m.width - k0);
                 t.ld_code = m.ldk;
                 t.ld_col = 1;
                 tiles.push_back(t);
@@ -661,6 +737,17 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    // the grouped profiles' descriptors and their merged {insert, background} tables
+    if (!c->mp_groups.empty())
+    {
+        HIP_TRY(c, c->d_mp_groups.alloc(c->mp_groups.size()));
+        HIP_TRY(c, hipMemcpy(c->d_mp_groups.p, c->mp_groups.data(), c->mp_groups.size() * sizeof(dcp_mp_group), hipMemcpyHostToDevice));
+        HIP_TRY(c, c->d_mp_in.alloc((size_t)mp_in_pairs * 2u));
+        dcp_launch_mp_in(c->d_mp_groups.p, (unsigned)c->mp_groups.size(), c->mp_first[1], kMpParts[0], kMpParts[1],
+                         c->d_emis_insert.p, c->d_emis_null.p, c->d_mp_in.p, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     c->rs_ready = expand_on_host != 0;
     c->nprof = nprofiles;
     return DCP_OK;
@@ -691,12 +778,11 @@ int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *c, unsigned p, float *out)
     for (dcp_prof_meta const &m : c->metas)
         if (m.pidx == p)
         {
-            std::vector<float> tab((size_t)DCP_NCODES * m.ldk);
-            HIP_TRY(c, hipMemcpy(tab.data(), c->d_emis_match.p + m.emis_off, tab.size() * sizeof(float),
-                                 hipMemcpyDeviceToHost));
+            // rows of (possibly shared) length ldk from the profile's first column to its last row's last node
+            std::vector<float> tab((size_t)(DCP_NCODES - 1) * m.ldk + m.core_size);
+            HIP_TRY(c, hipMemcpy(tab.data(), c->d_emis_match.p + m.emis_off, tab.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (unsigned code = 0; code < DCP_NCODES; ++code)
-                std::memcpy(out + (size_t)code * m.core_size, &tab[(size_t)code * m.ldk],
-                            sizeof(float) * m.core_size);
+                std::memcpy(out + (size_t)code * m.core_size, &tab[(size_t)code * m.ldk], sizeof(float) * m.core_size);
             return DCP_OK;
         }
     return DCP_EINVAL;
@@ -1480,6 +1566,38 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
             c->last_launches++;
             continue;
         }
+        // K profiles per wavefront: the class of at most 64 nodes always (855-890 Gcell/s against 600 with one node
+        // per lane); the class of 65 .. 128 nodes while the batch is small -- its one-profile kernels at six or seven
+        // wavefronts per SIMD are faster on a full grid (936 against 860 Gcell/s at 1 000 queries), slower below
+        // (profiles/r04/rowsweep_small_classes.txt)
+        bool const use_mp = k < 2 && c->mp_first[k + 1] > c->mp_first[k] &&
+                            (c->mp_mode == 1 || (c->mp_mode < 0 && (k == 0 || nq < kMpClass1MaxQueries)));
+        if (use_mp)
+        {
+            // The two smallest classes: K profiles per wavefront (viterbi_mp_kernel) for the grouped ones, the
+            // unstaged one-profile kernel on the column views of the flagged rest.
+            unsigned const g0 = c->mp_first[k], g1 = c->mp_first[k + 1];
+            if (g1 > g0)
+            {
+                a.mp_groups = c->d_mp_groups.p, a.mp_in = c->d_mp_in.p;
+                a.first_prof = g0, a.nprof = g1 - g0;
+                if (int lrc = dcp_launch_mp((int)kMpParts[k], &a, ls))
+                    return lrc == -2 ? c->fail(DCP_EINVAL, "scan too large for one launch") : c->fail(DCP_EFAIL, "no %u-profile kernel", kMpParts[k]);
+            }
+            if (c->mp_flagged_first[k])
+            {
+                a.first_prof = c->mp_flagged_first[k] - 1u, a.nprof = last - a.first_prof;
+                if (int lrc = dcp_launch_rowsweep_grid(sc.R, sc.W, &a, 0, 1u, ls, 0u, 0))
+                    return lrc == -2 ? c->fail(DCP_EINVAL, "scan too large for one launch") : c->fail(DCP_EFAIL, "no kernel for class R=%d W=%d", sc.R, sc.W);
+            }
+            a.first_prof = first, a.nprof = last - first;
+            HIP_TRY(c, hipEventRecord(c->ev_class[c->n_launched], ls));
+            if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_class[c->n_launched], 0));
+            c->launched_redo[c->n_launched] = false;
+            c->launched_class[c->n_launched++] = k;
+            c->last_launches++;
+            continue;
+        }
         int stg, pf;
         unsigned bw;
         rowsweep_variant(c, sc.R, sc.W, a.nchunks, &stg, &bw, &pf);
@@ -1541,6 +1659,7 @@ int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *c, int stg, unsigned bw)
     c->rs_force_pf = (int)((bw >> 16) & 1u);      // bit 16: the two-rows-ahead prefetch variant
     c->rs_force_R = (int)((bw >> 20) & 15u);      // bits 20..23: only the class with this many nodes per lane (0: all)
     c->seg_mode = ((bw >> 24) & 3u) == 1u ? 0 : ((bw >> 24) & 3u) == 2u ? 1 : -1; // bits 24..25: 1 = never the segmented sweep, 2 = always
+    c->mp_mode = ((bw >> 26) & 3u) == 1u ? 0 : ((bw >> 26) & 3u) == 2u ? 1 : -1;  // bits 26..27: 1 = never K profiles per wavefront, 2 = always
     return DCP_OK;
 }
 int dcp_gpu_test_set_seg_col_bytes(dcp_gpu_ctx *c, unsigned long long bytes)
@@ -1697,7 +1816,7 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
     {
         dcp_prof_meta const &m = c->metas[c->slot_of_pidx[hits[h].profile_idx]];
         uint64_t const L = c->seq_len[hits[h].seq_idx];
-        need[h] = 3ull * (L + 1) * m.ldk + 5ull * (L + 1);
+        need[h] = 3ull * (L + 1) * m.width + 5ull * (L + 1);
         cap[h] = (uint32_t)(2 * L + 2ull * m.core_size + 16);
     }
     uint64_t const budget = 1ull << 29; // floats (2 GiB) of work area per launch

@@ -14,11 +14,31 @@ struct dcp_prof_meta
     uint32_t ldk;       // padded node count = lanes * R of its size class
     uint32_t pidx;      // index in the caller's profile order
     uint32_t flags;     // DCP_PROF_EXACT_E
-    uint32_t reserved;
+    uint32_t width;     // this profile's own columns of a row: core_size + padding of -inf (= ldk unless the profile
+                        // shares its rows with others: dcp_mp_group)
 };
 // a finite MD or DD > 0: E(j) is not the maximum of the match states alone (a delete state may exceed every
 // match state before it), so the kernels take the delete states into E(j) for this profile
 #define DCP_PROF_EXACT_E 1u
+
+// Profiles of at most 128 nodes share their table rows with their neighbours (round 4): K of them side by side in one
+// table [1364][ldk] (and one transition block [8][ldk]), each followed by at least 8 columns of -inf, so that ONE
+// wavefront scores K (profile, query) pairs with the same query at once -- 64 / K lanes of four nodes each
+// (viterbi_mp_kernel).  A member's dcp_prof_meta is a column view of the group's table: emis_off / trans_off point at
+// its first column, ldk is the group's row length, width its own columns.  in_off: the group's [1364][K] table of
+// {insert, background} emissions (float2), one per-lane load per word instead of two scalar tables per profile.
+struct dcp_mp_group
+{
+    uint64_t emis_off;  // float offset of the group's table in emis_match
+    uint32_t trans_off; // float offset of its trans8 block
+    uint32_t ldk;       // row length (multiple of 4)
+    uint32_t in_off;    // float2 offset of its {eI, eN} table in mp_in
+    uint32_t nparts;    // members, 1..K
+    uint32_t col0[4];      // first column of each member (absent members: columns of -inf)
+    uint32_t core_size[4]; // 0 for an absent member
+    uint32_t pidx[4];      // caller's profile index
+    uint32_t slot[4];      // entry of profs[]
+};
 
 // a (query, profile) pair the query-lane kernel hands to the row-sweep kernel
 struct dcp_pair
@@ -64,6 +84,9 @@ struct dcp_scan_args
     float *seg_col0, *seg_col1; // 16 bytes per row
     unsigned seg_stride; // rows (of 16 bytes) per column, >= lmax + 2
     unsigned seg_index;  // this launch's segment
+    // profiles of at most 128 nodes, grid mode (viterbi_mp_kernel): first_prof / nprof then count GROUPS
+    dcp_mp_group const *mp_groups;
+    float const *mp_in; // {eI, eN} pairs: [group][1364][K]
     unsigned seg_q0, seg_nq; // the queries of this launch: q = seg_q0 .. seg_q0 + seg_nq - 1 (a chunk of the scan's, sized so that the columns fit)
     dcp_pair *seg_redo;
     unsigned *seg_redo_n;
@@ -202,6 +225,11 @@ unsigned dcp_rowsweep_tasks_per_block(int W);
 // segment a->seg_index of every pair of the launch's profiles x queries, one wavefront per pair, segments of 64 x R
 // nodes (R = 5..8); != 0: no such kernel
 int dcp_launch_segsweep(int R, dcp_scan_args const *a, unsigned nblocks, void *stream);
+// K = 2 or 4 profiles per wavefront (groups a->first_prof .. + a->nprof of a->mp_groups) x all queries; != 0: no such kernel
+int dcp_launch_mp(int K, dcp_scan_args const *a, void *stream);
+// the groups' {insert, background} tables: groups [0, n_first) hold k_first members per wavefront, the rest k_rest
+void dcp_launch_mp_in(dcp_mp_group const *groups, unsigned ngroups, unsigned n_first, unsigned k_first, unsigned k_rest,
+                      float const *emis_insert, float const *emis_null, float *out, void *stream);
 unsigned dcp_segsweep_blocks(unsigned nprof, unsigned nq); // grid of one segment launch over nprof profiles x nq queries
 // grid mode (all chunks x the profiles of one size class): stg = leading emission rows a block stages in LDS
 // (0, 20 or 84), bw = wavefronts per staged block; != 0 if there is no such kernel or the grid is too large

@@ -112,6 +112,36 @@ __device__ __forceinline__ float wave_max(float v)
         float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
 }
 
+// max over each PART of the wavefront -- 64 / K consecutive lanes, K = 2 or 4 -- returned in every lane of the part
+// (viterbi_mp_kernel: K profiles per wavefront).  Four rotations inside the rows of 16 lanes make every lane hold its
+// row's maximum (cheaper than wave_max: no lane read); for K = 2 row 1 / 3 then takes row 0 / 2's over (row_bcast:15),
+// lanes 31 and 63 are read, and each half picks its own.
+template <int K> __device__ __forceinline__ float part_max(float v)
+{
+    float r;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(v));
+    if constexpr (K == 4) return r;
+    else
+    {
+        static_assert(K == 2, "two or four profiles per wavefront");
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+            : "+v"(r));
+        float const lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 31));
+        float const hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
+        return (threadIdx.x & 32u) ? hi : lo;
+    }
+}
+
 // five candidates in two v_max3_f32 (the tree max(max(a, b), max(c, d)) has the shorter chain but is three
 // instructions, and the row is bound by VALU issue -- a v_max* costs 4.2 SIMD cycles on gfx950 whatever its
 // operand count: profiles/r03/valu_issue.txt); max is exact, so the grouping changes no result
@@ -267,7 +297,11 @@ __device__ __forceinline__ void chain_rest(float const (&a)[R], float (&d)[R], f
 // `fetch` loads the NEXT row's emissions into em / eN / eI; it is called as soon as this row
 // has consumed them (one set of registers, no copies), and its loads land during the
 // cross-lane part of the row.
-template <int R, int W, int PH, class Fetch>
+// PARTS > 1 (W == 1 only): the wavefront holds PARTS profiles side by side, 64 / PARTS lanes each (viterbi_mp_kernel):
+// E(j) is then a per-part maximum, a value per lane, and eN / eI arrive per lane; everything else is as for one
+// profile -- the edges into a profile's first node are -inf, so what the lane-shifts carry over from the neighbouring
+// part's last lane never counts.
+template <int R, int W, int PH, int PARTS = 1, class Fetch>
 __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                                          float (&em)[5][R], float (&em3)[R], float (&em4)[R], float (&em5)[R], float (&eN)[5], float (&eI)[5],
                                          LaneSpecial const &sp, float const xEB,
@@ -308,7 +342,8 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
 #pragma unroll
         for (int r = 1; r < R; ++r)
             em = fmaxf(em, m[r]);
-        E = wave_max(em);
+        if constexpr (PARTS == 1) E = wave_max(em);
+        else E = part_max<PARTS>(em);
     }
 
     // Delete chain D_k = max(M_{k-1} + MD_k, D_{k-1} + DD_k): sequential inside
@@ -671,7 +706,8 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
     constexpr bool PF2 = PF;
     constexpr int NEAR = STG >= 84 ? 7 : 3, FAR = 31 - NEAR; // word lengths read from LDS / from global memory
     __shared__ Exchange<(W > 1 ? W : 1)> xc_mem;
-    __shared__ __attribute__((aligned(16))) float stage_mem[STAGED > 0 ? STAGED * 64 * R : 4];
+    // (R <= 2: a profile that shares its rows with others owns core_size + 8 columns, up to 8 more than 64 x R)
+    __shared__ __attribute__((aligned(16))) float stage_mem[STAGED > 0 ? STAGED * (64 * R + (R <= 2 ? 8 : 0)) : 4];
     float const *const stg = stage_mem;
     Exchange<(W > 1 ? W : 1)> *xc = &xc_mem;
     unsigned const lane = threadIdx.x & 63u;
@@ -731,15 +767,22 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
     // re-materialised through a v_cndmask / v_cmp pair in every row)
     unsigned const exact_e = __builtin_amdgcn_readfirstlane(pm.flags & DCP_PROF_EXACT_E);
     unsigned const node0 = (W == 1 ? lane : wave * 64u + lane) * R; // this lane's first node
-    unsigned const lane_off = node0 < pm.core_size ? node0 : ldk - R; // past the last node: the row's -inf tail
+    // past the last node: R columns of the -inf padding behind the profile's own -- the first aligned ones if they
+    // fit (always, when the profile shares its rows with others: ldk is then the shared row's length), else the row's end
+    unsigned const m4 = (pm.core_size + 3u) & ~3u;
+    unsigned const lane_off = node0 < pm.core_size ? node0 : (m4 + R <= pm.width ? m4 : pm.width - R);
     unsigned gen = 0;
+    unsigned const swd = pm.width; // row length of the staged image: the profile's own columns
     if constexpr (STAGED > 0)
     {
-        // the first STAGED rows of the table are contiguous: [code][ldk]
-        float4 const *__restrict__ src = reinterpret_cast<float4 const *>(em_base);
-        float4 *dst = reinterpret_cast<float4 *>(stage_mem);
-        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * (ldk >> 2); i += blockDim.x) // ldk is a multiple of 4
-            dst[i] = src[i];
+        // the profile's columns of the table's first STAGED rows: [code][swd] in LDS (a stand-alone table's rows are
+        // that long and the copy is contiguous; a profile that shares its rows with others has them ldk apart)
+        unsigned const n4 = swd >> 2; // widths are multiples of 4
+        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * n4; i += blockDim.x)
+        {
+            unsigned const c = i / n4, k = i - c * n4;
+            reinterpret_cast<float4 *>(stage_mem + c * swd)[k] = reinterpret_cast<float4 const *>(em_base + (size_t)c * ldk)[k];
+        }
         __syncthreads();
     }
     if constexpr (W > 1)
@@ -808,17 +851,17 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
             float emg[2][3][R]; // [parity][three-, four-, five-base rows] (the three-base slot is unused with 84 rows staged)
             unsigned w1 = base_at(words, 0);                                   // window of row 1
             unsigned w2 = ((w1 << 2) | base_at(words, 1)) & 1023u;              // window of row 2
-            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg);
-            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, emg[1][0], emg[1][1], emg[1][2], eN, eI, stg);
-            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[0][0], emg[0][1], emg[0][2], eN, eI, stg);
+            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg, swd);
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, emg[1][0], emg[1][1], emg[1][2], eN, eI, stg, swd);
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[0][0], emg[0][1], emg[0][2], eN, eI, stg, swd);
 #define DCP_E3(PAR) (STG >= 84 ? em[2] : emg[PAR][0])
 #define DCP_ROW2(PH, PAR)                                                      \
     {                                                                          \
         w1 = w2;                                               /* row j + 1 */ \
         w2 = ((w2 << 2) | base_at(words, j + 1u)) & 1023u;     /* row j + 2 */ \
         o = dp_row<R, W, PH>(s, t, em, DCP_E3(PAR), emg[PAR][1], emg[PAR][2], eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
-            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg); \
-            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[PAR][0], emg[PAR][1], emg[PAR][2], eN, eI, stg); \
+            load_row<R, STAGED, NEAR, true>(em_base, ldk, lane_boff, eN_tab, eI_tab, w1, em, em[2], em[3], em[4], eN, eI, stg, swd); \
+            load_row<R, STAGED, FAR, false>(em_base, ldk, lane_boff, eN_tab, eI_tab, w2, em, emg[PAR][0], emg[PAR][1], emg[PAR][2], eN, eI, stg, swd); \
         });                                                                    \
         ++j;                                                                   \
     }
@@ -842,7 +885,7 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
         else
         {
         unsigned w = base_at(words, 0);
-        load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg);
+        load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg, swd);
 
 // compute row j from the tables in registers; once consumed they are refilled for row j+1
 // (the word one past the last base is padding: harmless)
@@ -850,7 +893,7 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
     {                                                                          \
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
         o = dp_row<R, W, PH>(s, t, em, em[2], em[3], em[4], eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
-            load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg); \
+            load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg, swd); \
         });                                                                    \
         ++j;                                                                   \
     }
@@ -885,6 +928,173 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
         }
     }
     if (!pair_mode) break; // grid mode: one task per block
+    }
+}
+
+// ============================================================================
+// K profiles per wavefront (round 4): the classes of at most 64 / at most 128 nodes, grid mode.
+// One node per lane (R = 1) pays a row's cross-lane work -- E(j)'s seven-step maximum, the delete chain's passes, the
+// lane shifts -- for 45 cells on average, two per lane for 95: 594 and 931 Gcell/s against 1 100-1 300 for the wider
+// classes.  Here K = 4 (at most 64 nodes) or 2 (at most 128) profiles share a wavefront, 64 / K lanes of FOUR nodes
+// each, scored against the SAME query: one sequence window, one set of special transitions, one row count for all
+// of them, a row's cross-lane work once for 180-190 cells.  The K profiles' tables lie side by side in one table
+// (dcp_mp_group), so a row is still one scalar row base + the lane's byte offset; E(j) is a per-part maximum
+// (part_max); the insert / background emissions come per lane from the group's [1364][K] float2 table.  A block is
+// four wavefronts on four consecutive queries of one group, with the table's 20 leading rows in LDS.
+// ============================================================================
+template <int K>
+__global__ __launch_bounds__(256, 3) void viterbi_mp_kernel(dcp_scan_args a) // (four wavefronts per SIMD at 128 VGPRs spill 44: 3 % slower)
+{
+    constexpr int R = 4;
+    constexpr unsigned PL = 64u / K;       // lanes per profile
+    constexpr unsigned MAXLD = 4u * 72u + 16u; // longest row of a group: 4 x (64 + 8) or 2 x (128 + 8) columns
+    constexpr int STAGED = 20;
+    __shared__ __attribute__((aligned(16))) float stage_mem[STAGED * MAXLD];
+    unsigned const lane = threadIdx.x & 63u;
+    unsigned const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned const nblk = gridDim.x; // multiple of 8
+    unsigned const vblk = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3); // XCD-aware, as in the row sweep
+    unsigned const bpp = (a.nseqs + 3u) / 4u; // blocks per group: four queries each
+    if (vblk >= a.nprof * bpp) return;
+    unsigned const g_rel = vblk / bpp;
+    unsigned const qi = (vblk - g_rel * bpp) * 4u + wave;
+    bool const has_q = qi < a.nseqs; // a spare wavefront only helps with the copy
+    unsigned const q = __builtin_amdgcn_readfirstlane(has_q ? qi : 0u);
+    dcp_mp_group const *gp = a.mp_groups + (a.first_prof + g_rel);
+    unsigned const ldk = __builtin_amdgcn_readfirstlane(gp->ldk);
+    unsigned const nparts = __builtin_amdgcn_readfirstlane(gp->nparts);
+    float const *__restrict__ em_base = a.emis_match + gp->emis_off;
+    {
+        // the group's table is a stand-alone [1364][ldk]: its first STAGED rows are contiguous
+        float4 const *__restrict__ src = reinterpret_cast<float4 const *>(em_base);
+        float4 *dst = reinterpret_cast<float4 *>(stage_mem);
+        for (unsigned i = threadIdx.x; i < (unsigned)STAGED * (ldk >> 2); i += 256u)
+            dst[i] = src[i];
+        __syncthreads();
+    }
+    if (!has_q) return;
+    float const *const stg = stage_mem;
+    float const ni = neg_inf();
+    unsigned const part = lane / PL, pl = lane % PL;
+    unsigned const M = gp->core_size[part];
+    unsigned const node0 = pl * R;
+    // past the profile's last node (or an absent member): the four aligned columns of -inf behind it
+    unsigned const lane_off = gp->col0[part] + (node0 < M ? node0 : ((M + 3u) & ~3u));
+    Trans<R> t;
+    {
+        float const *__restrict__ tb = a.trans8 + gp->trans_off + lane_off;
+        VecLoad<R>::ld(tb + (size_t)DCP_T_ENTRY * ldk, t.ent);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MM * ldk, t.mm);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_IM * ldk, t.im);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_DM * ldk, t.dm);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MD * ldk, t.md);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_DD * ldk, t.dd);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_MI * ldk, t.mi);
+        VecLoad<R>::ld(tb + (size_t)DCP_T_II * ldk, t.ii);
+    }
+    // {eI, eN} of word code c for this lane's profile: in_tab[c][part]
+    float2 const *__restrict__ in_tab = reinterpret_cast<float2 const *>(a.mp_in) + gp->in_off;
+    unsigned part_boff = part * 8u;
+
+    unsigned const L = a.seq_len[q];
+    cu32 *words = as_const(a.seq_words + a.seq_woff[q]);
+    cfloat *xt = as_const(a.xtrans + (size_t)q * DCP_XSTRIDE);
+    unsigned const x = lane & 3u; // this lane's special state: 0 N, 1 J, 2 C, 3 R
+    LaneSpecial sp;
+    sp.a = x == 1u ? xt[DCP_X_EJ] : x == 2u ? xt[DCP_X_EC] : ni;
+    sp.b = x == 0u ? xt[DCP_X_NN] : x == 1u ? xt[DCP_X_JJ] : x == 2u ? xt[DCP_X_CC] : xt[DCP_X_RR];
+    sp.c = x == 0u ? xt[DCP_X_NB] : x == 1u ? xt[DCP_X_JB] : ni;
+    float const xEB = xt[DCP_X_EB];
+
+    PairState<R> s;
+#pragma unroll
+    for (int h = 0; h < 5; ++h)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            s.P[h][r] = ni, s.Q[h][r] = ni;
+        s.PX[h] = ni;
+    }
+    {
+        float const B0 = 0.0f + xt[DCP_X_SB];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            s.P[0][r] = B0 + t.ent[r];
+        s.PX[0] = x == 0u ? 0.0f + xt[DCP_X_SN] : x == 3u ? 0.0f : ni;
+    }
+
+    float em[5][R], eN[5], eI[5];
+    RowOut o{ni, ni};
+    unsigned j = 1;
+    unsigned lane_boff = lane_off * 4u;
+    unsigned gen = 0;
+    // one row's inputs: the match emission rows (two from LDS, three from global memory: load_row) and the lane's
+    // {eI, eN} pairs -- scalar row pointer + the lane's part offset, like the emission rows
+    auto fetch_in = [&](unsigned w) {
+        load_row<R, STAGED, 31, false>(em_base, ldk, lane_boff, nullptr, nullptr, w, em, em[2], em[3], em[4], eN, eI, stg);
+        asm volatile("" : "+v"(part_boff));
+#pragma unroll
+        for (int l = 1; l <= 5; ++l)
+        {
+            gchar_ptr row = (gchar_ptr)in_tab + code_of(w, l) * (unsigned)K * 8u;
+            asm volatile("" : "+s"(row));
+            float2 const v = *(float2 const *)(row + part_boff);
+            eI[l - 1] = v.x, eN[l - 1] = v.y;
+        }
+    };
+    unsigned w = base_at(words, 0);
+    fetch_in(w);
+#define DCP_MROW(PH)                                                                                   \
+    {                                                                                                 \
+        w = ((w << 2) | base_at(words, j)) & 1023u;                                                   \
+        o = dp_row<R, 1, PH, K>(s, t, em, em[2], em[3], em[4], eN, eI, sp, xEB, nullptr, wave, lane, gen, 0u, \
+                                [&]() { fetch_in(w); });                                              \
+        ++j;                                                                                          \
+    }
+    while (j + 4 <= L)
+    {
+        DCP_MROW(1) DCP_MROW(2) DCP_MROW(3) DCP_MROW(4) DCP_MROW(0)
+    }
+    if (j <= L) DCP_MROW(1)
+    if (j <= L) DCP_MROW(2)
+    if (j <= L) DCP_MROW(3)
+    if (j <= L) DCP_MROW(4)
+#undef DCP_MROW
+
+    // C(L) and R(L) sit in lanes 2 and 3 of every quad: the first lane of each part takes its own quad's
+    float const C = dpp_mov<0xAA /*quad_perm:[2,2,2,2]*/, 0xf, 0xf>(o.X, o.X);
+    float const nul = dpp_mov<0xFF /*quad_perm:[3,3,3,3]*/, 0xf, 0xf>(o.X, o.X);
+    float const alt = fmaxf(o.E + xt[DCP_X_ET], C + xt[DCP_X_CT]);
+    if (pl == 0u && part < nparts)
+    {
+        unsigned const pidx = gp->pidx[part];
+        size_t const oi = (size_t)q * a.nprof_total + pidx;
+        if (a.out_null) a.out_null[oi] = nul;
+        if (a.out_alt) a.out_alt[oi] = alt;
+        // xmath_lrt_f32 + filter of scan_thread.c:121-123
+        float const lrt = -2 * (nul - alt);
+        if (__builtin_isfinite(lrt) && !(lrt < a.lrt_threshold))
+        {
+            unsigned const h = atomicAdd(a.nhits, 1u);
+            if (h < a.hit_cap) a.hits[h] = dcp_hit{a.q_base + q, pidx, nul, alt};
+        }
+    }
+}
+
+// the groups' {insert, background} tables from the per-profile ones: out[(in_off + c * K + part)] = {eI, eN}
+__global__ __launch_bounds__(256) void mp_in_kernel(dcp_mp_group const *groups, unsigned n_first, unsigned k_first, unsigned k_rest,
+                                                    float const *emis_insert, float const *emis_null, float *out)
+{
+    dcp_mp_group const g = groups[blockIdx.x];
+    unsigned const K = blockIdx.x < n_first ? k_first : k_rest;
+    float2 *dst = reinterpret_cast<float2 *>(out) + g.in_off;
+    for (unsigned i = threadIdx.x; i < (unsigned)DCP_NCODES * K; i += 256u)
+    {
+        unsigned const c = i / K, part = i - c * K;
+        // an absent member: -inf (its lanes' values are never used, but must not be NaN sources)
+        float2 v{neg_inf(), neg_inf()};
+        if (part < g.nparts) v = float2{emis_insert[(size_t)g.pidx[part] * DCP_NCODES + c], emis_null[(size_t)g.pidx[part] * DCP_NCODES + c]};
+        dst[i] = v;
     }
 }
 
@@ -1118,7 +1328,7 @@ struct TraceView
     float const *eM, *eI, *eN;
     float const *xt;
     uint32_t const *words;
-    unsigned ldk, M, L;
+    unsigned ldk, wd, M, L; // ldk: row length of the tables (shared rows: the group's); wd: the profile's own columns = row length of Mv / Iv / Dv
 };
 
 __device__ __forceinline__ unsigned window_at(uint32_t const *words, unsigned j)
@@ -1138,7 +1348,7 @@ __device__ float trace_P(TraceView const &v, unsigned jj, unsigned k, int *arg)
     int a = -1;
     if (k > 0)
     {
-        size_t const o = (size_t)jj * v.ldk + k - 1;
+        size_t const o = (size_t)jj * v.wd + k - 1;
         float c0 = v.Mv[o] + v.mm[k], c1 = v.Iv[o] + v.im[k], c2 = v.Dv[o] + v.dm[k];
         if (c0 > best) best = c0, a = 0;
         if (c1 > best) best = c1, a = 1;
@@ -1153,7 +1363,7 @@ __device__ float trace_P(TraceView const &v, unsigned jj, unsigned k, int *arg)
 // Q_k(jj): best predecessor of I_k; *arg: 0 = M_k, 1 = I_k
 __device__ float trace_Q(TraceView const &v, unsigned jj, unsigned k, int *arg)
 {
-    size_t const o = (size_t)jj * v.ldk + k;
+    size_t const o = (size_t)jj * v.wd + k;
     float best = -__builtin_inff();
     int a = -1;
     float c0 = v.Mv[o] + v.mi[k], c1 = v.Iv[o] + v.ii[k];
@@ -1209,6 +1419,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
 
     TraceView v;
     v.ldk = pm.ldk;
+    v.wd = pm.width;
     v.M = pm.core_size;
     v.L = a.seq_len[q];
     v.words = a.seq_words + a.seq_woff[q];
@@ -1221,7 +1432,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
     v.eM = a.emis_match + pm.emis_off;
     v.eI = a.emis_insert + (size_t)pm.pidx * DCP_NCODES;
     v.eN = a.emis_null + (size_t)pm.pidx * DCP_NCODES;
-    unsigned const L = v.L, ldk = v.ldk;
+    unsigned const L = v.L, ldk = v.wd; // (the work arrays' row length: the profile's own columns)
     size_t const mat = (size_t)(L + 1) * ldk;
     float *work = a.work + a.work_off[h];
     v.Mv = work, v.Iv = work + mat, v.Dv = work + 2 * mat;
@@ -1301,7 +1512,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
             for (unsigned l = 1; l <= maxl; ++l)
             {
                 unsigned const c = code_of(w, (int)l);
-                m = fmaxf(m, trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * ldk + k]);
+                m = fmaxf(m, trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * v.ldk + k]);
                 iv = fmaxf(iv, trace_Q(v, j - l, k, nullptr) + v.eI[c]);
             }
             Mj[k] = m, Ij[k] = iv;
@@ -1402,7 +1613,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
             {
                 unsigned const c = code_of(w, (int)l);
                 float sc;
-                if (st == ST_M) sc = trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * ldk + k];
+                if (st == ST_M) sc = trace_P(v, j - l, k, nullptr) + v.eM[(size_t)c * v.ldk + k];
                 else if (st == ST_I) sc = trace_Q(v, j - l, k, nullptr) + v.eI[c];
                 else if (st == ST_N) sc = trace_PN(v, j - l, nullptr) + v.eN[c];
                 else if (st == ST_J) sc = trace_PJ(v, j - l, nullptr) + v.eN[c];
@@ -1647,7 +1858,7 @@ extern "C" unsigned dcp_rowsweep_max_block_waves(int R, int W, int stg)
     if (stg == 84) return R >= 1 && R <= 7 ? (unsigned)rs_block_threads(R, 1, 84) / 64u : 0u; // R = 8: 172 KB
     return 0u;
 }
-extern "C" unsigned dcp_rowsweep_stage_bytes(int R, int stg) { return (unsigned)stg * 64u * (unsigned)R * 4u; }
+extern "C" unsigned dcp_rowsweep_stage_bytes(int R, int stg) { return (unsigned)stg * (64u * (unsigned)R + (R <= 2 ? 8u : 0u)) * 4u; }
 
 // Grid mode: all chunks x the profiles [first_prof, first_prof + nprof) of one size class.
 //   stg  rows staged in LDS (0: every wavefront its own task, four per block);
@@ -1683,6 +1894,23 @@ extern "C" int dcp_launch_rowsweep_grid(int R, int W, dcp_scan_args const *a, in
 #undef DCP_CASE_S
     if (stg != 0) return -1;
     return dcp_launch_rowsweep(R, W, a, nblocks, stream);
+}
+
+extern "C" int dcp_launch_mp(int K, dcp_scan_args const *a, void *stream)
+{
+    uint64_t nb = (uint64_t)a->nprof * ((a->nseqs + 3u) / 4u);
+    nb = (nb + 7u) / 8u * 8u;
+    if (nb > 0x7fffffffull) return -2;
+    if (K == 4) hipLaunchKernelGGL((viterbi_mp_kernel<4>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (K == 2) hipLaunchKernelGGL((viterbi_mp_kernel<2>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *a);
+    else return -1;
+    return 0;
+}
+extern "C" void dcp_launch_mp_in(dcp_mp_group const *groups, unsigned ngroups, unsigned n_first, unsigned k_first, unsigned k_rest,
+                                 float const *emis_insert, float const *emis_null, float *out, void *stream)
+{
+    hipLaunchKernelGGL(mp_in_kernel, dim3(ngroups), dim3(256), 0, (hipStream_t)stream, groups, n_first, k_first, k_rest,
+                       emis_insert, emis_null, out);
 }
 
 // blocks of a segment launch: four queries of one profile each, rounded up to the XCD count

@@ -314,7 +314,8 @@ int dcp_gpu_test_set_seg_col_bytes(dcp_gpu_ctx *, unsigned long long bytes);
  * LDS (0, 20 or 84) and, in `block_waves`: bits 0..7 wavefronts per block (0: the default), bits 8..15 KiB of
  * unused LDS per block (an occupancy experiment), bit 16 the two-rows-ahead prefetch variant, bits 20..23 the
  * one size class (nodes per lane) to force, 0 = all, bits 24..25 the segmented sweep of the classes of more than
- * 512 nodes (1 never, 2 always, 0 the library's rule) -- instead of the one the library picks per size class and
+ * 512 nodes (1 never, 2 always, 0 the library's rule), bits 26..27 likewise the K-profiles-per-wavefront kernel of
+ * the classes of at most 128 nodes -- instead of the one the library picks per size class and
  * batch size; stage < 0 restores the automatic choice.  A class without such a kernel keeps the automatic
  * one.  Every variant computes the same scores: tests/test_gpu_parity.py runs them all against the oracle. */
 int dcp_gpu_test_set_rowsweep_variant(dcp_gpu_ctx *, int stage_rows, unsigned block_waves);

@@ -648,6 +648,67 @@ def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves,
         hooks_scanner.test_set_rowsweep_variant(-1, 0)
 
 
+@pytest.mark.parametrize("nsmall", [1, 2, 3, 4, 5, 9])
+def test_profiles_sharing_a_wavefront_bit_exact(dcp, oracle32, scanner, nsmall):
+    """Profiles of at most 128 nodes in grid mode (viterbi_mp_kernel): four (at most 64 nodes) or two (65 .. 128) of them
+    share one wavefront -- 16 / 32 lanes of four nodes each, their tables side by side in one table, E(j) a per-part
+    maximum, insert / background emissions per lane -- and are scored against the same query together.  Group sizes
+    that do not fill a wavefront (1, 2, 3, 5, 9 profiles of a class: absent members' lanes run on -inf), core sizes at
+    both ends of each class and 1 .. 5 nodes, a flagged (positive MD / DD) profile in each class (never grouped: the
+    one-profile kernel on its own columns), planted hits, 1 .. 21 queries incl. every tail of the five-row unrolling:
+    bit for bit against the oracle's float32 recursion on the product's tables, multi- and uni-hit; the traceback
+    and the table read-back work on a member's column view."""
+    rng = np.random.default_rng(700 + nsmall)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    small = [1, 2, 3, 5, 17, 33, 47, 63, 64][:nsmall] if nsmall < 9 else [1, 2, 3, 5, 17, 33, 47, 63, 64]
+    mid = [65, 66, 90, 127, 128][:max(1, min(5, nsmall))]
+    sizes = small + mid + [300]
+    params = [pfam_like_params(rng, M) for M in sizes]
+    for M in (40, 100):  # one flagged profile per class
+        null, match, trans = pfam_like_params(rng, M)
+        trans = trans.copy()
+        trans[1:M, 2] = np.float32(0.7)
+        trans[1:M, 6] = np.float32(0.4)
+        params.append((null, match, trans))
+        sizes.append(M)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    oprofs = [oracle32.new(*prm, ENTRY_DIST_OCCUPANCY, 0.01) for prm in params]
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    scanner.upload_db(profiles, expand_on_host=True)
+    hit_p = len(small) - 1                  # the largest of the small ones
+    hit_q = len(small)                      # 65 nodes
+    for nseq in (1, 6, 21):
+        seqs = ([rng.integers(0, 4, L, dtype=np.uint8) for L in range(1, 22)] if nseq == 21 else rand_seqs(rng, nseq, 1, 300))
+        if nseq == 6:
+            seqs[1] = planted_query(rng, oprofs[hit_p], sizes[hit_p], flank=7)
+            seqs[4] = planted_query(rng, oprofs[hit_q], sizes[hit_q], flank=11)
+        scanner.upload_seqs(seqs)
+        for multi in (True, False):
+            on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, multi, False, True)
+            scanner.scan(multi, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+            gn, ga = scanner.scores()
+            assert same_bits(gn, on) and same_bits(ga, oa), (nsmall, nseq, multi)
+            hits = scanner.hits()
+            lrt = np.float32(-2) * (on - oa)
+            want = {(int(q), int(p)) for q, p in zip(*np.nonzero(np.isfinite(lrt) & ~(lrt < np.float32(10.0))))}
+            assert {(int(h["seq_idx"]), int(h["profile_idx"])) for h in hits} == want
+            if nseq == 6 and sizes[hit_p] >= 17:
+                assert (1, hit_p) in want and (4, hit_q) in want
+                # the traceback reads a member's columns of the shared table
+                sel = np.array([h for h in hits if (int(h["seq_idx"]), int(h["profile_idx"])) in ((1, hit_p), (4, hit_q))], dcp.HIT_DTYPE)
+                paths, alt = scanner.trace_paths(sel, multi, False)
+                for h, path, a in zip(sel, paths, alt):
+                    assert len(path) > 0 and np.float32(a) == h["alt_loglik"]
+                    assert int(path["seqlen"].sum()) == len(seqs[int(h["seq_idx"])])
+    # the query-lane kernels' redo pairs of these classes go through the one-profile kernel on the same views
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_QLANE2)
+    qn, qa = scanner.scores()
+    scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+    rn, ra = scanner.scores()
+    assert same_bits(qn, rn) and same_bits(qa, ra)
+
+
 @pytest.mark.parametrize("multi", [True, False])
 def test_segmented_sweep_bit_exact(dcp, oracle32, hooks_scanner, multi):
     """Profiles of more than 512 nodes in grid mode: one wavefront per pair, the profile cut into segments of 384 nodes
