@@ -618,7 +618,10 @@ def test_rowsweep_variants_bit_exact(dcp, oracle32, hooks_scanner, stage, waves,
     or two DP rows ahead (sequences of 1..150 nt: every length of the ten-row unrolling's tail) -- against the
     oracle's float32 recursion on the product's tables, bit for bit, over every one-wavefront size class, a
     flagged (positive MD / DD) profile and multi-wavefront classes (which have one variant).  Forced through the
-    tests' own -DDCP_TEST_HOOKS build; the shipped library picks among the same kernels by batch size."""
+    tests' own -DDCP_TEST_HOOKS build; the shipped library picks among the same kernels by batch size.  (Since round 4
+    the two smallest classes run K profiles per wavefront at these batch sizes, whatever variant is forced --
+    test_profiles_sharing_a_wavefront_bit_exact -- and their one-profile kernels, which read a member's columns of the
+    shared table, are forced in test_one_profile_kernels_on_shared_tables.)"""
     rng = np.random.default_rng(4242)
     cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
     sizes = (1, 5, 64, 65, 127, 128, 150, 192, 250, 256, 257, 320, 384, 448, 449, 512, 600)
@@ -707,6 +710,33 @@ def test_profiles_sharing_a_wavefront_bit_exact(dcp, oracle32, scanner, nsmall):
     scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
     rn, ra = scanner.scores()
     assert same_bits(qn, rn) and same_bits(qa, ra)
+
+
+@pytest.mark.parametrize("stage,waves,prefetch2", [(0, 4, 0), (20, 4, 0), (84, 8, 0), (20, 16, 1)])
+def test_one_profile_kernels_on_shared_tables(dcp, oracle32, hooks_scanner, stage, waves, prefetch2):
+    """The one-profile kernels of the two smallest classes (what the 65 .. 128-node class runs from 96 queries on) read
+    a profile's COLUMNS of a table it shares with its neighbours: the staged image is a strided copy, a lane past the
+    last node reads the padding behind the profile's own columns.  Forced through the tests' build (bits 26..27: never K
+    profiles per wavefront) in every staging variant, bit for bit against the oracle."""
+    rng = np.random.default_rng(31337)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    sizes = (1, 4, 31, 64, 65, 99, 121, 125, 128, 64, 3, 128, 70)
+    params = [pfam_like_params(rng, M) for M in sizes]
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    hooks_scanner.upload_db(profiles, expand_on_host=True)
+    try:
+        hooks_scanner.test_set_rowsweep_variant(stage, waves | (prefetch2 << 16) | (1 << 26))
+        for nseq in (2, 21):
+            seqs = ([rng.integers(0, 4, L, dtype=np.uint8) for L in range(1, 22)] if nseq == 21 else rand_seqs(rng, nseq, 30, 200))
+            hooks_scanner.upload_seqs(seqs)
+            hooks_scanner.scan(True, False, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+            gn, ga = hooks_scanner.scores()
+            on, oa = oracle_dp_on_product_tables(dcp, oracle32, hooks_scanner, profiles, seqs, True, False, True)
+            assert same_bits(gn, on) and same_bits(ga, oa), (stage, waves, prefetch2, nseq)
+    finally:
+        hooks_scanner.test_set_rowsweep_variant(-1, 0)
 
 
 @pytest.mark.parametrize("multi", [True, False])
