@@ -40,7 +40,7 @@ constexpr SizeClass kClasses[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}
                                   {3, 4}, {4, 4}, {3, 8}, {4, 8}, {3, 16}, {4, 16}};
 // cells/s of each class on a full grid, measured on the C3 DB (profiles/r03/rowsweep_variants.txt; round 2:
 // profiles/r02/rowsweep_tuning.txt): the kernel choice prices a row-sweep scan with them
-constexpr double kClassRate[] = {600e9, 930e9, 1120e9, 1250e9, 1240e9, 1320e9, 1220e9, 1230e9,
+constexpr double kClassRate[] = {880e9, 930e9, 1120e9, 1250e9, 1240e9, 1320e9, 1220e9, 1230e9,
                                  830e9, 960e9, 820e9, 600e9, 600e9, 600e9}; // multi-wavefront classes: the segmented sweep (round 4: profiles/r04/rowsweep_multiwave.txt)
 constexpr int kNumClasses = (int)(sizeof kClasses / sizeof kClasses[0]);
 static_assert(sizeof kClassRate / sizeof kClassRate[0] == sizeof kClasses / sizeof kClasses[0], "one rate per class");
