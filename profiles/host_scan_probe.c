@@ -5,7 +5,9 @@
  *
  *   gcc -std=gnu11 -O2 -I include profiles/host_scan_probe.c -o /tmp/host_scan_probe \
  *       -L deciphon-old_amd -ldeciphon_host -ldcp_hip -lm -fopenmp -Wl,-rpath,$PWD/deciphon-old_amd
- *   /tmp/host_scan_probe [nprofiles=2000] [nseqs=2000] [seq_len=1000] [batch=1000] [lrt_threshold=10]
+ *   /tmp/host_scan_probe [nprofiles=2000] [nseqs=2000] [seq_len=1000] [batch=1000] [lrt_threshold=10] [batch_symbols=0]
+ *   seq_len = 0: mixed lengths, log-uniform on 100 .. 10 000 nt (BASELINE configs[4]'s queries); batch_symbols: a device
+ *   pass also closes at that many bases (scan_cfg.batch_symbols; the scan_run adapter asks for 2 Mi)
  *
  * Core sizes: the lognormal draw of BASELINE config C3 restated with this file's own generator (median 150,
  * sigma 0.6, clipped to 30..2000); sequences uniform over ACGT.  Prints one line per phase. */
@@ -53,6 +55,7 @@ int main(int argc, char **argv)
     unsigned const len = argc > 3 ? (unsigned)atoi(argv[3]) : 1000u;
     unsigned const batch = argc > 4 ? (unsigned)atoi(argv[4]) : 1000u;
     double const threshold = argc > 5 ? atof(argv[5]) : 10.0; /* 1e30: no hits, i.e. no traceback and no product rows */
+    unsigned long const batch_symbols = argc > 6 ? strtoul(argv[6], NULL, 10) : 0ul;
 
     struct imm_nuclt const *nuclt = imm_super(&imm_dna_iupac);
     struct imm_nuclt_code code;
@@ -108,29 +111,38 @@ int main(int argc, char **argv)
     if (nseqs == 0) return remove(path), 0;
 
     struct scan_seq *seqs = calloc(nseqs, sizeof *seqs);
-    char *text = malloc((size_t)nseqs * (len + 1u));
+    unsigned *lens = malloc((size_t)nseqs * sizeof *lens);
+    size_t total_len = 0;
     for (unsigned q = 0; q < nseqs; ++q)
     {
-        char *s = text + (size_t)q * (len + 1u);
-        for (unsigned i = 0; i < len; i += 32)
+        lens[q] = len ? len : (unsigned)(exp(log(100.0) + next_unit() * log(100.0)) + 0.5); /* 100 .. 10 000, log-uniform */
+        total_len += lens[q];
+    }
+    char *text = malloc(total_len + nseqs);
+    size_t at = 0;
+    for (unsigned q = 0; q < nseqs; ++q)
+    {
+        char *s = text + at;
+        for (unsigned i = 0; i < lens[q]; i += 32)
         {
             uint64_t r = next_u64();
-            for (unsigned k = 0; k < 32 && i + k < len; ++k, r >>= 2)
+            for (unsigned k = 0; k < 32 && i + k < lens[q]; ++k, r >>= 2)
                 s[i + k] = "ACGT"[r & 3u];
         }
-        s[len] = '\0';
+        s[lens[q]] = '\0';
         seqs[q].id = (int64_t)q + 1;
         seqs[q].data = s;
+        at += lens[q] + 1u;
     }
 
-    double const cells = sum_core * (double)nseqs * (double)len;
+    double const cells = sum_core * (double)total_len;
     /* job 0 includes the first-use costs (module load); jobs 0 and 1 load the database like the reference's
      * scan_run does per job; job 1 leaves it resident (cfg.keep_resident) and job 2 picks it up */
     for (int job = 0; job < 3; ++job)
     {
         struct list_src src = {seqs, nseqs, 0};
         struct scan_cfg cfg = {.scan_id = 1, .multi_hits = true, .hmmer3_compat = false, .lrt_threshold = threshold,
-                               .batch = batch, .balance_by_cells = true, .keep_resident = job >= 1};
+                               .batch = batch, .balance_by_cells = true, .keep_resident = job >= 1, .batch_symbols = batch_symbols};
         t0 = now();
         enum rc rc = scan_run_source(path, cfg, 1, list_src_next, &src);
         double const dt = now() - t0;
@@ -140,13 +152,15 @@ int main(int argc, char **argv)
         for (int ch; (ch = fgetc(prods)) != EOF;)
             rows += ch == '\n';
         prod_final_cleanup();
-        printf("scan_run_source job %d%s: %u seqs x %u nt, batch %u: %.3f s wall = %.1f Gcell/s end to end (file -> resident DB -> "
-               "products), %ld product rows, %.1f seqs/s\n",
-               job, job == 2 ? " (database resident from job 1)" : "", nseqs, len, batch, dt, cells / dt / 1e9, rows, nseqs / dt);
+        printf("scan_run_source job %d%s: %u seqs x %s nt (%zu bases), passes of <= %u seqs / %lu bases: %.3f s wall = %.1f Gcell/s end to "
+               "end (file -> resident DB -> products), %ld product rows, %.1f seqs/s\n",
+               job, job == 2 ? " (database resident from job 1)" : "", nseqs, len ? "fixed" : "100-10000", total_len, batch,
+               batch_symbols, dt, cells / dt / 1e9, rows, nseqs / dt);
     }
     scan_resident_release();
     remove(path);
     free(text);
+    free(lens);
     free(seqs);
     return 0;
 }
