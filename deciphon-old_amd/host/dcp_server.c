@@ -633,6 +633,11 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     if (!db_filename || !next_seq) return fail(RC_EINVAL, "bad scan arguments");
     if (nthreads == 0 || nthreads > NUM_THREADS) return fail(RC_EINVAL, "bad number of threads");
     unsigned const batch = cfg.batch ? cfg.batch : 1;
+    /* A pass may grow to one and a half times its target when the source ends inside it (below): the host copies
+     * of a pass and the look-ahead queue are sized for that. */
+    unsigned const limit_n = batch + batch / 2u;
+    unsigned long const limit_s = cfg.batch_symbols + cfg.batch_symbols / 2u;
+    unsigned const qcap = limit_n + 1u;
     /* the partitions' host threads (one per device) each fan out once more: unpacking a partition and formatting a
      * batch's product rows are many-core jobs of their own */
     int const omp_levels = omp_get_max_active_levels();
@@ -652,6 +657,11 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     struct imm_seq *bseq[2] = {NULL, NULL};
     int64_t *bid[2] = {NULL, NULL};
     char **btext[2] = {NULL, NULL};
+    char **qtext = NULL; /* look-ahead queue: sequences fetched from the source, not yet in a pass */
+    int64_t *qid = NULL;
+    unsigned long *qlen = NULL;
+    unsigned qn = 0;
+    unsigned long qs = 0;
     bool db_open = false, reader_open = false, have_stat = false;
     struct stat st;
     unsigned nparts = 0;
@@ -675,12 +685,15 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     /* two host copies of a batch (A/B): while batch i is scanned, batch i-1's rows are still being written */
     for (int k = 0; k < 2; ++k)
     {
-        bseq[k] = malloc((size_t)batch * sizeof *bseq[k]);
-        bid[k] = malloc((size_t)batch * sizeof *bid[k]);
-        btext[k] = calloc(batch, sizeof *btext[k]);
+        bseq[k] = malloc((size_t)limit_n * sizeof *bseq[k]);
+        bid[k] = malloc((size_t)limit_n * sizeof *bid[k]);
+        btext[k] = calloc(limit_n, sizeof *btext[k]);
     }
     pend = calloc(nparts ? nparts : 1, sizeof *pend);
-    if (!th || !pend || !bseq[0] || !bseq[1] || !bid[0] || !bid[1] || !btext[0] || !btext[1])
+    qtext = calloc(qcap, sizeof *qtext);
+    qid = malloc((size_t)qcap * sizeof *qid);
+    qlen = malloc((size_t)qcap * sizeof *qlen);
+    if (!qtext || !qid || !qlen || !th || !pend || !bseq[0] || !bseq[1] || !bid[0] || !bid[1] || !btext[0] || !btext[1])
     {
         rc = fail(RC_ENOMEM, "alloc scan");
         goto cleanup;
@@ -721,18 +734,22 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
      * overlap; with one batch in flight per partition a sequence buffer is reused two batches later. */
     unsigned npend = 0;  /* sequences of the batch whose rows are still to be written */
     int cur = 0;         /* host copy the next batch is fetched into */
-    for (bool more = true; more && !rc;)
+    /* Passes are cut from a look-ahead queue.  A pass's target is `batch` sequences or cfg.batch_symbols bases,
+     * whichever comes first; the queue is filled until it exceeds one and a half targets or the source ends.  If the
+     * source ends while the queue is within one and a half targets, the whole queue is ONE pass -- a job never ends in
+     * a sliver of a pass, which costs a mixed-length job as much device time as a full one (the pass's longest
+     * sequence bounds it: DESIGN.md 4.3c) -- otherwise the pass is the shortest prefix that reaches a target. */
+    bool src_end = false;
+    for (; !rc;)
     {
-        /* prefetch up to `batch` sequences; each is copied, the source may reuse its buffer (scan.c:227-229) */
-        unsigned nb = 0;
-        unsigned long symbols = 0; /* of this pass: it also closes at cfg.batch_symbols (a pass is sized by work) */
-        while (nb < batch && (cfg.batch_symbols == 0 || nb == 0 || symbols < cfg.batch_symbols))
+        /* each sequence is copied, the source may reuse its buffer (scan.c:227-229) */
+        while (!src_end && qn <= limit_n && (cfg.batch_symbols == 0 || qs <= limit_s) && qn < qcap)
         {
             struct scan_seq s = {0, NULL};
             enum rc r = next_seq(arg, &s);
             if (r == RC_END)
             {
-                more = false;
+                src_end = true;
                 break;
             }
             if (r || !s.data)
@@ -740,19 +757,38 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
                 rc = r ? r : fail(RC_EINVAL, "sequence source returned no data");
                 break;
             }
-            free(btext[cur][nb]);
-            btext[cur][nb] = strdup(s.data);
-            if (!btext[cur][nb])
+            qtext[qn] = strdup(s.data);
+            if (!qtext[qn])
             {
                 rc = fail(RC_ENOMEM, "alloc sequence");
                 break;
             }
-            bseq[cur][nb] = imm_seq(imm_str(btext[cur][nb]), abc);
-            bid[cur][nb] = s.id;
-            symbols += (unsigned long)strlen(btext[cur][nb]);
-            ++nb;
+            qid[qn] = s.id;
+            qlen[qn] = (unsigned long)strlen(qtext[qn]);
+            qs += qlen[qn];
+            ++qn;
         }
-        if (rc || nb == 0) break;
+        if (rc || qn == 0) break;
+        unsigned nb = 0;
+        if (src_end && qn <= limit_n && (cfg.batch_symbols == 0 || qs <= limit_s)) nb = qn; /* the job's last pass */
+        else
+        {
+            unsigned long symbols = 0;
+            while (nb < qn && nb < batch && (cfg.batch_symbols == 0 || nb == 0 || symbols < cfg.batch_symbols))
+                symbols += qlen[nb++];
+        }
+        for (unsigned i = 0; i < nb; ++i)
+        {
+            free(btext[cur][i]);
+            btext[cur][i] = qtext[i];
+            bseq[cur][i] = imm_seq(imm_str(btext[cur][i]), abc);
+            bid[cur][i] = qid[i];
+            qs -= qlen[i];
+        }
+        memmove(qtext, qtext + nb, (size_t)(qn - nb) * sizeof *qtext);
+        memmove(qid, qid + nb, (size_t)(qn - nb) * sizeof *qid);
+        memmove(qlen, qlen + nb, (size_t)(qn - nb) * sizeof *qlen);
+        qn -= nb;
         enum rc shared = RC_OK;
         if (nparts == 0) continue; /* an empty database: every sequence is consumed, nothing is scored */
         int const prev = cur ^ 1;
@@ -829,10 +865,13 @@ cleanup:
         batch_result_free(&pend[i]);
     for (int k = 0; k < 2; ++k)
     {
-        for (unsigned i = 0; btext[k] && i < batch; ++i)
+        for (unsigned i = 0; btext[k] && i < limit_n; ++i)
             free(btext[k][i]);
         free(btext[k]), free(bid[k]), free(bseq[k]);
     }
+    for (unsigned i = 0; qtext && i < qn; ++i)
+        free(qtext[i]);
+    free(qtext), free(qid), free(qlen);
     free(pend), free(th);
     if (reader_open) profile_reader_del(reader);
     if (db_open) db_reader_close(&db->super);

@@ -860,12 +860,16 @@ struct scan_cfg
      * (integration/scan_run_adapter.c turns it into api_increment_job_progress).  NULL = no reporting. */
     void (*progress)(unsigned long pairs, void *arg);
     void *progress_arg;
-    /* A device pass is sized by WORK, not only by count: it closes when `batch` sequences are fetched or when
-     * their lengths add up to batch_symbols (0 = no such bound), whichever comes first -- at least one sequence.
-     * The cells of a pass are (sum of the partition's core sizes) x (symbols of the pass), so with sequences of
-     * 100 nt .. 10 kbp a count-sized pass varies a hundredfold in device time and a short one cannot fill the
-     * query-lane kernels' lanes (BASELINE configs[4] "dynamic batching").  Within a pass the device packs the
-     * sequences by length itself (include/dcp_gpu.h, dcp_plan_query_slots); product rows keep the source's order. */
+    /* A device pass is sized by WORK, not only by count: its target is `batch` sequences or batch_symbols bases
+     * (0 = no such bound), whichever comes first -- at least one sequence.  The cells of a pass are (sum of the
+     * partition's core sizes) x (symbols of the pass), so with sequences of 100 nt .. 10 kbp a count-sized pass varies
+     * a hundredfold in device time and a short one cannot fill the query-lane kernels' lanes (BASELINE configs[4]
+     * "dynamic batching").  Passes are cut from a look-ahead queue filled until it exceeds one and a half targets or
+     * the source ends: if the source ends within one and a half targets the queue is ONE pass (a job never ends in a
+     * sliver of a pass -- with mixed lengths that costs as much device time as a full one), otherwise the pass is the
+     * shortest prefix that reaches a target.  batch = 1 keeps the reference's loop shape.  Within a pass the device
+     * packs the sequences by length itself (include/dcp_gpu.h, dcp_plan_query_slots); product rows keep the source's
+     * order. */
     unsigned long batch_symbols;
 };
 void scan_resident_release(void);

@@ -32,15 +32,17 @@
 
 #include <string.h>
 
-/* A device pass is sized by work (BASELINE configs[4] "dynamic batching"): it closes at
- * SCAN_RUN_BATCH_SYMBOLS bases -- about 2 000 sequences of 1 kbp, or 1 000 of a 100 nt .. 10 kbp mix, some five seconds
- * of device time against a Pfam-sized partition -- or at SCAN_RUN_BATCH sequences (what the host buffers are sized for),
- * whichever comes first.  Inside a pass the device packs the sequences by length into its wavefront slots. */
+/* A device pass is sized by work (BASELINE configs[4] "dynamic batching"): its target is
+ * SCAN_RUN_BATCH_SYMBOLS bases -- about 4 000 sequences of 1 kbp, or 2 000 of a 100 nt .. 10 kbp mix, some ten seconds
+ * of device time against a Pfam-sized partition -- or SCAN_RUN_BATCH sequences, whichever comes first; a job's last
+ * pass takes up to one and a half targets rather than leaving a sliver (scan_cfg.batch_symbols, deciphon_host.h).
+ * Inside a pass the device packs the sequences by length into its wavefront slots; the larger the pass, the less its
+ * longest sequence weighs (profiles/r04/host_scan_probe.txt). */
 #ifndef SCAN_RUN_BATCH
-#define SCAN_RUN_BATCH 16384
+#define SCAN_RUN_BATCH 32768
 #endif
 #ifndef SCAN_RUN_BATCH_SYMBOLS
-#define SCAN_RUN_BATCH_SYMBOLS (2ul << 20)
+#define SCAN_RUN_BATCH_SYMBOLS (4ul << 20)
 #endif
 
 /* one scan at a time per process, like the reference's file-scope `scan`, `api_rc`, `db` (scan.c:41-43) */

@@ -464,6 +464,45 @@ static char *run_sized(struct scan_seq const *seqs, unsigned n, unsigned batch, 
     prod_final_cleanup();
     return text;
 }
+/* the rule of scan_run_source (include/deciphon_host.h, struct scan_cfg), restated: passes are cut from a look-ahead queue
+ * that is filled until it EXCEEDS one and a half targets (batch sequences, batch_symbols bases) or the source ends; if the
+ * source has ended and the queue is within one and a half targets, it is one pass; else the pass is the shortest prefix
+ * that reaches a target */
+static unsigned long expected_passes(unsigned long const *len, unsigned n, unsigned batch, unsigned long symbols)
+{
+    unsigned const limit_n = batch + batch / 2u;
+    unsigned long const limit_s = symbols + symbols / 2u;
+    unsigned next = 0, qn = 0;
+    unsigned long qs = 0, passes = 0;
+    unsigned long q[64];
+    bool end = false;
+    for (;;)
+    {
+        while (!end && qn <= limit_n && (symbols == 0 || qs <= limit_s))
+        {
+            if (next == n)
+            {
+                end = true;
+                break;
+            }
+            q[qn++] = len[next], qs += len[next++];
+        }
+        if (qn == 0) return passes;
+        unsigned nb = 0;
+        if (end && qn <= limit_n && (symbols == 0 || qs <= limit_s)) nb = qn;
+        else
+        {
+            unsigned long s = 0;
+            while (nb < qn && nb < batch && (symbols == 0 || nb == 0 || s < symbols))
+                s += q[nb++];
+        }
+        for (unsigned i = 0; i < nb; ++i)
+            qs -= q[i];
+        memmove(q, q + nb, (qn - nb) * sizeof *q);
+        qn -= nb;
+        ++passes;
+    }
+}
 static void passes_sized_by_symbols(void)
 {
     enum { NSEQ = 9 };
@@ -485,20 +524,20 @@ static void passes_sized_by_symbols(void)
     unsigned long const pairs = g_pairs;
     CHECK(g_passes == 1 && pairs > 0);
     char *by_work = run_sized(seqs, NSEQ, 100, 60); /* a pass closes once it holds >= 60 symbols */
-    unsigned long want = 0, acc = 0;
-    for (unsigned q = 0; q < NSEQ; ++q)
-    {
-        acc += len[q];
-        if (acc >= 60 || q + 1 == NSEQ) ++want, acc = 0;
-    }
-    CHECK(want >= 3 && g_passes == want && g_pairs == pairs);
+    unsigned long const want = expected_passes(len, NSEQ, 100, 60);
+    CHECK(want >= 3 && want < NSEQ && g_passes == want && g_pairs == pairs);
     CHECK(strcmp(by_count, by_work) == 0); /* same rows, same order */
     char *one_each = run_sized(seqs, NSEQ, 100, 1); /* every pass holds at least one sequence */
-    CHECK(g_passes == NSEQ && g_pairs == pairs && strcmp(by_count, one_each) == 0);
-    char *count_first = run_sized(seqs, NSEQ, 2, total); /* the count bound closes the pass first */
-    CHECK(g_passes == (NSEQ + 1) / 2 && strcmp(by_count, count_first) == 0);
+    CHECK(g_passes == NSEQ && expected_passes(len, NSEQ, 100, 1) == NSEQ && g_pairs == pairs && strcmp(by_count, one_each) == 0);
+    /* the count bound closes the passes first: 2, 2, 2 -- and the last three sequences are ONE pass: the source ends
+     * within one and a half targets, so the job does not finish on a sliver */
+    char *count_first = run_sized(seqs, NSEQ, 2, total);
+    CHECK(g_passes == 4 && expected_passes(len, NSEQ, 2, total) == 4 && strcmp(by_count, count_first) == 0);
+    /* batch = 1 is still the reference's loop shape: one sequence per pass */
+    char *ref_shape = run_sized(seqs, NSEQ, 1, 0);
+    CHECK(g_passes == NSEQ && strcmp(by_count, ref_shape) == 0);
     CHECK(strstr(by_count, "9\t3002\t") != NULL && strstr(by_count, "9\t3007\t") != NULL);
-    free(by_count), free(by_work), free(one_each), free(count_first);
+    free(by_count), free(by_work), free(one_each), free(count_first), free(ref_shape);
 }
 
 static void scan_run_batched(void)
