@@ -746,7 +746,7 @@ def test_segmented_sweep_bit_exact(dcp, oracle32, hooks_scanner, multi):
     column parked in HBM between launches (viterbi_segment_kernel), B(j) = N(j) + NB, and the pairs whose E -> B /
     J -> B feedback beat that B -- planted hits here, in a 384- and in a 512-node-segment class -- finished by the exact
     multi-wavefront kernel behind it.  Forced on for every batch size through the test-hooks build (the library uses it
-    from 32 queries on), against the oracle's float32 recursion on the product's tables, bit for bit; every multi-
+    once a class has 4 096 pairs), against the oracle's float32 recursion on the product's tables, bit for bit; every multi-
     wavefront class at both ends of its range (two to eight segments; profiles of one class with different segment
     counts side by side); a flagged (positive MD / DD) profile goes to the exact kernel whole; with a column budget of a
     few hundred KB a class's queries are swept chunk by chunk."""
