@@ -537,13 +537,14 @@ def roofline_block(timed, dcp, workload, steps, sizes, b, e, qstep, world, qlen)
     #               plus every tile image once per (profile, 256-query block)
     #   compulsory: SURVEY 8d note 2 -- 548*M + L + 8 bytes per pair (compact profile streamed once)
     ntiles = (sizes[b:e].astype(np.int64) + 7) // 8
-    lanes = ((qstep // world + 63) // 64) * 64 if qlen else None
+    # (weak scaling: every rank scans ALL `qstep` queries of the step against its shard b..e)
+    lanes = ((qstep + 63) // 64) * 64 if qlen else None
     two_stage = timed.kernel == dcp.KERNEL_QLANE2
     hbm_boundaries = ((ntiles - 1) // 2) if two_stage else (ntiles - 1)  # odd -> even only / every boundary
     scratch_bytes = (int(24 * int(hbm_boundaries.sum()) * lanes * qlen) if (is_qlane and qlen) else None)
-    tile_bytes = (int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep // world + 255) // 256) if is_qlane else None)
-    npairs_launch = (e - b) * (qstep // world)
-    compulsory = int(548 * int(sizes[b:e].sum()) * (qstep // world) + (qlen + 8) * npairs_launch) if qlen else None
+    tile_bytes = (int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep + 255) // 256) if is_qlane else None)
+    npairs_launch = (e - b) * qstep
+    compulsory = int(548 * int(sizes[b:e].sum()) * qstep + (qlen + 8) * npairs_launch) if qlen else None
     roof = {
         "bound": "valu-issue",
         "kernel": kname,
@@ -635,6 +636,9 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=-1,
                     help="steps of the end-to-end leg (each step uploads its own sequences, scans, fetches the hits "
                          "to the host); default min(steps, 5), 0 = skip")
+    ap.add_argument("--as-rank", default="", metavar="R/N",
+                    help="one-GPU rehearsal of an N-GPU run's rank R: this GPU holds shard R of N of the DB and scans the "
+                         "N x larger query step an N-GPU run uses (value = this one rank's rate; --gpus 1 only)")
     ap.add_argument("--stub-scan", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU (gloo)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--stub-sleep", type=float, default=0.0, help=argparse.SUPPRESS)  # seconds per stub step
@@ -680,18 +684,25 @@ def main():
     wl = WORKLOADS[args.workload]
     nprof = args.nprof or wl["nprof"]
     qlen = args.qlen or wl["qlen"]
-    qstep = (args.qstep or wl["qstep"]) * world
+    shape_rank, shape_world = rank, world
+    if args.as_rank:
+        if world != 1:
+            sys.exit("--as-rank is a one-GPU rehearsal: run it with --gpus 1")
+        shape_rank, shape_world = (int(x) for x in args.as_rank.split("/"))
+        if not 0 <= shape_rank < shape_world:
+            sys.exit("--as-rank R/N needs 0 <= R < N")
+    qstep = (args.qstep or wl["qstep"]) * shape_world
     sizes = core_sizes_for(args.workload, nprof)
 
     # ---- resident DB shard -------------------------------------------------------------
     t0 = time.perf_counter()
-    b, e = ddist.shard_range(sizes, world, rank)
+    b, e = ddist.shard_range(sizes, shape_world, shape_rank)
     cfg = dcp.ProteinCfg(dcp.ENTRY_DIST_OCCUPANCY, 0.01)
     nthreads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
     if args.dense:
         fam = [dcp.ProteinProfile.sample(0xDEC1F0 + f, int(sizes[f]), cfg, f"FAM{f:02d}") for f in range(args.dense)]
         sizes = np.array([sizes[p % args.dense] for p in range(nprof)], np.uint32)
-        b, e = ddist.shard_range(sizes, world, rank)
+        b, e = ddist.shard_range(sizes, shape_world, shape_rank)
         profiles = [fam[p % args.dense] for p in range(b, e)]
     else:
         with ThreadPoolExecutor(max(1, nthreads // max(1, min(world, 8)))) as ex:
@@ -919,6 +930,9 @@ def main():
                 "dense_families": args.dense or None, "dense_queries": (None if not args.dense else
                                                                          "random" if args.dense_random else "consensus"),
                 "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({cdist_state['kind']})" if (world > 1 or force_dist) else ""),
+                "rehearsal": (None if not args.as_rank else
+                              f"rank {shape_rank} of {shape_world} on ONE GPU: profiles {b}..{e} (sum M {int(sizes[b:e].sum())}) x the "
+                              f"{qstep}-query step of a {shape_world}-GPU run; value is this one rank's rate, not a {shape_world}-GPU figure"),
             },
             "roofline": roof,
             "multi_gpu": multi_gpu,

@@ -130,3 +130,26 @@ def test_rowsweep_run_is_labelled_rowsweep():
     assert roof["kernel"] == "viterbi_rowsweep_kernel<R=3,W=1>"
     assert roof["traffic"] is None and roof["hbm"]["achieved_frac"] is None
     assert roof["l2_gather"] is not None and roof["lds"] is None
+
+
+def test_a_rank_of_eight_counts_all_the_step_s_queries():
+    """Weak scaling: with N ranks the step has N x 1 000 queries and EVERY rank scans all of them against its shard.  The
+    analytic byte figures of the block are per launch of that rank (until round 4 they divided the step's queries by N)."""
+    bench = load_bench()
+    sizes = bench.core_sizes_for("c3", 20000)
+    world, qstep, qlen, steps = 8, 8000, 1000, 2
+    b, e = 2500, 5000
+    sc = StubScanner(int(sizes[b:e].sum()), qlen)
+
+    def step(i):
+        sc.scan(q_range=(i * qstep, (i + 1) * qstep))
+
+    timed = bench.timed_leg(sc, step, 0, steps, lambda: None)
+    roof = bench.roofline_block(timed, DCP, "c3", steps, sizes, b, e, qstep, world, qlen)
+    sum_m = int(sizes[b:e].sum())
+    assert roof["cells_per_launch"] == sum_m * qstep * qlen
+    assert roof["hbm"]["compulsory_bytes_per_launch"] == 548 * sum_m * qstep + (qlen + 8) * (e - b) * qstep
+    ntiles = (sizes[b:e].astype(np.int64) + 7) // 8
+    assert roof["hbm"]["analytic_scratch_plane_bytes_per_launch"] == 24 * int(((ntiles - 1) // 2).sum()) * qstep * qlen
+    assert roof["hbm"]["analytic_tile_image_bytes_per_launch"] == int(ntiles.sum()) * 8 * 1364 * 4 * ((qstep + 255) // 256)
+    assert roof["traffic"] is None  # the committed counters are those of the one-GPU command
