@@ -181,6 +181,7 @@ def _load(path=None, hooks=False):
         sig["dcp_gpu_test_set_rowsweep_variant"] = (I, [P, I, U])
         sig["dcp_gpu_test_set_ring_stall"] = (I, [P, I])
         sig["dcp_gpu_test_set_seg_col_bytes"] = (I, [P, C.c_ulonglong])
+        sig["dcp_gpu_test_set_trace_mode"] = (I, [P, I, C.c_ulonglong])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -573,6 +574,11 @@ class Scanner:
     def test_set_seg_col_bytes(self, nbytes):
         """TEST-ONLY (test-hooks build): cap on a size class's boundary columns in the segmented row sweep (0: default)."""
         self._check(self._lib.dcp_gpu_test_set_seg_col_bytes(self._c, int(nbytes)))
+
+    def test_set_trace_mode(self, own_forward, budget_floats=0):
+        """TEST-ONLY (test-hooks build): trace_paths' forward pass by the trace kernel's own loop (1) or the row-sweep
+        kernels (0, the default); budget_floats: work area per round of launches (0: default)."""
+        self._check(self._lib.dcp_gpu_test_set_trace_mode(self._c, int(bool(own_forward)), int(budget_floats)))
 
     def test_set_rowsweep_variant(self, stage_rows, block_waves=0):
         """TEST-ONLY (test-hooks build): force the grid-mode row-sweep kernel variant; stage_rows < 0: automatic."""

@@ -195,6 +195,9 @@ struct dcp_gpu_ctx
     int launched_class[kMaxLaunches] = {0};
     bool launched_redo[kMaxLaunches] = {false}; // the exact kernel behind a segmented sweep: its cells are counted there
     // segmented sweep of the multi-wavefront classes (grid mode): per-class scratch columns and redo lists
+    DevBuf<float> d_trace_work;   // the traceback's work areas (kept between calls, grows to the largest round)
+    int trace_mode = 0;            // test hook: 1 = the trace kernel's own forward loop instead of the row sweep's
+    uint64_t trace_budget = 0;     // test hook: floats of work area per round of launches (0 = 2^31)
     DevBuf<float> d_seg_scratch;
     DevBuf<dcp_pair> d_seg_redo;
     DevBuf<unsigned> d_seg_redo_n; // [DCP_MAX_CLASSES]
@@ -1679,6 +1682,13 @@ int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *c, int on)
     c->ring_stall = on ? 1u : 0u;
     return DCP_OK;
 }
+int dcp_gpu_test_set_trace_mode(dcp_gpu_ctx *c, int own_forward, unsigned long long budget_floats)
+{
+    if (!c) return DCP_EINVAL;
+    c->trace_mode = own_forward ? 1 : 0;
+    c->trace_budget = budget_floats;
+    return DCP_OK;
+}
 int dcp_gpu_test_set_redo_cap(dcp_gpu_ctx *c, unsigned cap)
 {
     if (!c) return DCP_EINVAL;
@@ -1814,17 +1824,31 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
     if (int rc = ensure_xtrans(c, multi_hits, hmmer3_compat)) return rc;
     if (int rc = ensure_rowsweep_layout(c)) return rc;
 
+    // Forward pass: the row-sweep kernel of the profile's size class in pair mode, every row's values written to the
+    // hit's work area (viterbi_rowsweep_kernel<R, W, 0, false, TRACE>: the scan's own rows, ~0.1 us each); then one
+    // wavefront per hit walks back (viterbi_trace_kernel).  Until round 4 the forward pass was that kernel's own
+    // one-wavefront loop over rows held in global memory (5-7 us per row: a job of 3 000 sequences of up to 10 kbp spent
+    // 5 of its 23 s there, profiles/r04/host_scan_probe.txt); it is kept as the tests' second implementation
+    // (trace_mode) and for the null model's one-state path.
+    bool const sweep_forward = !null_model && c->trace_mode != 1;
     // per-hit work area and step capacity
     std::vector<uint64_t> need(nhits);
-    std::vector<uint32_t> cap(nhits);
+    std::vector<uint32_t> cap(nhits), wld(nhits);
+    std::vector<int> cls(nhits);
     for (unsigned h = 0; h < nhits; ++h)
     {
-        dcp_prof_meta const &m = c->metas[c->slot_of_pidx[hits[h].profile_idx]];
+        unsigned const slot = c->slot_of_pidx[hits[h].profile_idx];
+        dcp_prof_meta const &m = c->metas[slot];
         uint64_t const L = c->seq_len[hits[h].seq_idx];
-        need[h] = 3ull * (L + 1) * m.width + 5ull * (L + 1);
+        int k = 0;
+        while (k + 1 < kNumClasses && slot >= c->class_first[k + 1])
+            ++k;
+        cls[h] = k;
+        wld[h] = sweep_forward ? 64u * (unsigned)kClasses[k].R * (unsigned)kClasses[k].W : m.width;
+        need[h] = 3ull * (L + 1) * wld[h] + 5ull * (L + 1);
         cap[h] = (uint32_t)(2 * L + 2ull * m.core_size + 16);
     }
-    uint64_t const budget = 1ull << 29; // floats (2 GiB) of work area per launch
+    uint64_t const budget = c->trace_budget ? c->trace_budget : 1ull << 31; // floats (8 GiB) of work area per round of launches
     int rc = DCP_OK;
     uint64_t total_steps = 0;
     std::vector<dcp_step> host_steps;
@@ -1835,30 +1859,90 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
         while (h1 < nhits && (h1 == h0 || work + need[h1] <= budget))
             work += need[h1], scap += cap[h1], ++h1;
         unsigned const n = h1 - h0;
+        // this round's hits in size-class order (the forward launches take contiguous pair lists); results go back
+        // to the caller's order on the host
+        std::vector<unsigned> ord(n);
+        for (unsigned i = 0; i < n; ++i)
+            ord[i] = h0 + i;
+        if (sweep_forward) std::stable_sort(ord.begin(), ord.end(), [&](unsigned x, unsigned y) { return cls[x] < cls[y]; });
         std::vector<uint64_t> woff(n);
-        std::vector<uint32_t> soff(n + 1, 0);
+        std::vector<uint32_t> soff(n + 1, 0), ld(n);
+        std::vector<dcp_hit> shits(n);
+        std::vector<dcp_pair> pairs(n);
+        unsigned cfirst[kNumClasses + 1] = {0};
         uint64_t acc = 0;
         for (unsigned i = 0; i < n; ++i)
         {
+            unsigned const h = ord[i];
             woff[i] = acc;
-            acc += need[h0 + i];
-            soff[i + 1] = soff[i] + cap[h0 + i];
+            acc += need[h];
+            soff[i + 1] = soff[i] + cap[h];
+            ld[i] = wld[h];
+            shits[i] = hits[h];
+            pairs[i] = dcp_pair{hits[h].seq_idx, c->slot_of_pidx[hits[h].profile_idx]}; // {q, slot}
+            cfirst[cls[h] + 1] = i + 1u;
         }
-        DevBuf<float> d_work, d_alt;
+        for (int k = 1; k <= kNumClasses; ++k)
+            if (cfirst[k] < cfirst[k - 1]) cfirst[k] = cfirst[k - 1];
+        if (c->d_trace_work.n < work) HIP_TRY(c, c->d_trace_work.alloc(work));
+        DevBuf<float> d_alt;
         DevBuf<uint64_t> d_woff;
-        DevBuf<uint32_t> d_soff, d_nsteps;
+        DevBuf<uint32_t> d_soff, d_nsteps, d_ld, d_counts;
         DevBuf<dcp_step> d_steps;
         DevBuf<dcp_hit> d_hits;
-        HIP_TRY(c, d_work.alloc(work));
+        DevBuf<dcp_pair> d_pairs;
         HIP_TRY(c, d_alt.alloc(n));
         HIP_TRY(c, d_woff.alloc(n));
         HIP_TRY(c, d_soff.alloc(n + 1));
         HIP_TRY(c, d_nsteps.alloc(n));
+        HIP_TRY(c, d_ld.alloc(n));
         HIP_TRY(c, d_steps.alloc(scap));
         HIP_TRY(c, d_hits.alloc(n));
         HIP_TRY(c, hipMemcpy(d_woff.p, woff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_soff.p, soff.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d_hits.p, hits + h0, n * sizeof(dcp_hit), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_ld.p, ld.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_hits.p, shits.data(), n * sizeof(dcp_hit), hipMemcpyHostToDevice));
+        if (sweep_forward)
+        {
+            unsigned counts[kNumClasses];
+            for (int k = 0; k < kNumClasses; ++k)
+                counts[k] = cfirst[k + 1] - cfirst[k];
+            HIP_TRY(c, d_pairs.alloc(n));
+            HIP_TRY(c, d_counts.alloc(kNumClasses));
+            HIP_TRY(c, hipMemcpy(d_pairs.p, pairs.data(), n * sizeof(dcp_pair), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(d_counts.p, counts, sizeof counts, hipMemcpyHostToDevice));
+            dcp_scan_args fa{};
+            fa.profs = c->d_metas.p;
+            fa.emis_match = c->d_emis_match.p;
+            fa.emis_insert = c->d_emis_insert.p;
+            fa.emis_null = c->d_emis_null.p;
+            fa.trans8 = c->d_trans8.p;
+            fa.seq_words = c->d_seq_words.p;
+            fa.seq_woff = c->d_seq_woff.p;
+            fa.seq_len = c->d_seq_len.p;
+            fa.xtrans = c->d_xtrans.p;
+            fa.nprof_total = c->nprof;
+            fa.nprof = c->nprof;
+            fa.nseqs = c->nseqs;
+            fa.qchunk = 1u;
+            fa.nchunks = c->nseqs;
+            fa.trace_work = c->d_trace_work.p;
+            for (int k = 0; k < kNumClasses; ++k)
+            {
+                if (counts[k] == 0u) continue;
+                SizeClass const sc = kClasses[k];
+                fa.pairs = d_pairs.p + cfirst[k];
+                fa.npairs = d_counts.p + k;
+                fa.pair_cap = counts[k];
+                fa.trace_woff = d_woff.p + cfirst[k];
+                fa.trace_alt = d_alt.p + cfirst[k];
+                unsigned const tpb = dcp_rowsweep_tasks_per_block(sc.W);
+                unsigned const nb = ((counts[k] + tpb - 1u) / tpb + 7u) / 8u * 8u;
+                if (dcp_launch_trace_forward(sc.R, sc.W, &fa, nb, c->stream))
+                    return c->fail(DCP_EFAIL, "no traceback kernel for class R=%d W=%d", sc.R, sc.W);
+            }
+            HIP_TRY(c, hipGetLastError());
+        }
         dcp_trace_args ta{};
         ta.profs = c->d_metas.p;
         ta.slot_of_pidx = c->d_slot_of_pidx.p;
@@ -1872,37 +1956,45 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
         ta.xtrans = c->d_xtrans.p;
         ta.hits = d_hits.p;
         ta.nhits = n;
-        ta.work = d_work.p;
+        ta.work = c->d_trace_work.p;
         ta.work_off = d_woff.p;
         ta.steps = d_steps.p;
         ta.step_off = d_soff.p;
         ta.nsteps = d_nsteps.p;
         ta.alt_out = d_alt.p;
         ta.null_model = null_model ? 1 : 0;
+        ta.skip_forward = sweep_forward ? 1 : 0;
+        ta.work_ld = d_ld.p;
         dcp_launch_trace(&ta, n, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         std::vector<uint32_t> ns(n);
         std::vector<dcp_step> st(scap);
+        std::vector<float> alts(n);
         HIP_TRY(c, hipMemcpy(ns.data(), d_nsteps.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(st.data(), d_steps.p, scap * sizeof(dcp_step), hipMemcpyDeviceToHost));
-        if (alt_out) HIP_TRY(c, hipMemcpy(alt_out + h0, d_alt.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(alts.data(), d_alt.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        // back to the caller's order
+        std::vector<unsigned> at(n);
         for (unsigned i = 0; i < n; ++i)
+            at[ord[i] - h0] = i;
+        for (unsigned j = 0; j < n; ++j)
         {
+            unsigned const i = at[j], h = h0 + j;
+            if (alt_out) alt_out[h] = alts[i];
             if (ns[i] == 0xffffffffu)
             {
-                rc = c->fail(DCP_EFAIL, "pair (seq %u, profile %u) has no finite alt path",
-                             hits[h0 + i].seq_idx, hits[h0 + i].profile_idx);
+                rc = c->fail(DCP_EFAIL, "pair (seq %u, profile %u) has no finite alt path", hits[h].seq_idx, hits[h].profile_idx);
                 ns[i] = 0;
             }
-            else if (ns[i] > cap[h0 + i])
+            else if (ns[i] > cap[h])
             {
-                rc = c->fail(DCP_EFAIL, "path of hit %u exceeds its step capacity", h0 + i);
+                rc = c->fail(DCP_EFAIL, "path of hit %u exceeds its step capacity", h);
                 ns[i] = 0;
             }
             host_steps.insert(host_steps.end(), st.begin() + soff[i], st.begin() + soff[i] + ns[i]);
             total_steps += ns[i];
-            step_off[h0 + i + 1] = (uint32_t)total_steps;
+            step_off[h + 1] = (uint32_t)total_steps;
         }
         h0 = h1;
     }

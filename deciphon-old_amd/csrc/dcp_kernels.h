@@ -91,6 +91,12 @@ struct dcp_scan_args
     dcp_pair *seg_redo;
     unsigned *seg_redo_n;
     unsigned seg_redo_cap;
+    // traceback's forward pass (dcp_launch_trace_forward, pair mode): pair i's work area starts at trace_work +
+    // trace_woff[i] -- M, I, D as [L + 1][64 R W] each, then N, B, E, J, C as [L + 1] each -- and its alt score
+    // goes to trace_alt[i]
+    float *trace_work;
+    uint64_t const *trace_woff;
+    float *trace_alt;
 };
 
 // One 64-column tile of the expansion kernel.
@@ -131,6 +137,8 @@ struct dcp_trace_args
     uint32_t *nsteps;         // [nhits] steps written; 0xffffffff = no path
     float *alt_out;           // [nhits] log-likelihood recomputed by the trace
     int null_model;           // 0: alt model path (S..T); 1: null model path (R steps)
+    int skip_forward;         // the work areas are filled (dcp_launch_trace_forward): walk back only
+    uint32_t const *work_ld;  // [nhits] row length of each hit's M / I / D matrices, or NULL = the profile's own columns
 };
 
 // ---- query-lane kernel (dcp_qlane.hip) --------------------------------------
@@ -246,6 +254,7 @@ unsigned dcp_qlane2_lds_bytes(void);
 int dcp_launch_qlane_w3(dcp_qlane_args const *a, unsigned nblocks, void *stream);
 int dcp_launch_qlane_transpose(dcp_qlane_args const *a, unsigned nt, void *stream);
 void dcp_launch_trace(dcp_trace_args const *a, unsigned nhits, void *stream);
+int dcp_launch_trace_forward(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream);
 unsigned dcp_qlane_block_size(void);
 unsigned dcp_qlane_tile_nodes(void);
 unsigned dcp_qlane_scratch_planes(void);

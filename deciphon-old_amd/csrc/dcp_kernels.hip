@@ -301,13 +301,19 @@ __device__ __forceinline__ void chain_rest(float const (&a)[R], float (&d)[R], f
 // E(j) is then a per-part maximum, a value per lane, and eN / eI arrive per lane; everything else is as for one
 // profile -- the edges into a profile's first node are -inf, so what the lane-shifts carry over from the neighbouring
 // part's last lane never counts.
-template <int R, int W, int PH, int PARTS = 1, class Fetch>
+// `sink` (traceback only, viterbi_rowsweep_kernel<..., TRACE>): called once per row with the row's M, I, D of this lane's
+// nodes, E(j), this lane's special and B(j); the scoring kernels pass nothing.
+struct NoSink
+{
+    template <class... A> __device__ __forceinline__ void operator()(A const &...) const {}
+};
+template <int R, int W, int PH, int PARTS = 1, class Fetch, class Sink = NoSink>
 __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
                                          float (&em)[5][R], float (&em3)[R], float (&em4)[R], float (&em5)[R], float (&eN)[5], float (&eI)[5],
                                          LaneSpecial const &sp, float const xEB,
                                          Exchange<(W > 1 ? W : 1)> *xc,
                                          unsigned wave, unsigned lane,
-                                         unsigned &gen, unsigned const exact_e, Fetch &&fetch)
+                                         unsigned &gen, unsigned const exact_e, Fetch &&fetch, Sink &&sink = Sink{})
 {
     constexpr int s1 = (PH + 4) % 5, s2 = (PH + 3) % 5, s3 = (PH + 2) % 5,
                   s4 = (PH + 1) % 5, s5 = PH;
@@ -473,6 +479,7 @@ __device__ __forceinline__ RowOut dp_row(PairState<R> &s, Trans<R> const &t,
 
     // B(j) = max(N + NB, E + EB, J + JB)   (S(j>0) = -inf): lanes t & 3 = 0, 1 hold N, J
     float const B = fmaxf(quad_max(X + sp.c), E + xEB);
+    sink(m, ins, d, E, X, B);
 
     // predecessors leaving this row (overwrite the slot of row j-5)
     s.P[PH][0] = fmaxf(fmaxf(B + t.ent[0], shr1_add<XW>(m[R - 1], m_first, t.mm[0])),
@@ -696,10 +703,14 @@ constexpr int rs_block_threads(int R, int W, int STG, bool PF = false)
 }
 // PF (staged variants): the rows that still come from global memory are fetched TWO DP rows ahead -- the variants of
 // the small batches, which wait for HBM latency (one query: a wavefront's row takes as long as its loads).
-template <int R, int W, int STG, bool PF>
-__global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W, (STG == 20 && !PF) || (STG == 0 && W == 1 && DCP_RS_PAIR_BIG))) void viterbi_rowsweep_kernel(dcp_scan_args a)
+// TRACE (pair mode, unstaged): the forward half of the traceback -- the same rows, and every row's M, I, D of every node and
+// its N, B, E, J, C go to the pair's work area (dcp_scan_args::trace_work + trace_woff[task]: three matrices [L + 1][64 R W]
+// and five vectors [L + 1]); no score or hit record is written, the pair's alt score goes to trace_alt[task].
+template <int R, int W, int STG, bool PF, bool TRACE = false>
+__global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), TRACE ? (W > 4 ? 1 : 2) : rs_min_waves(R, W, (STG == 20 && !PF) || (STG == 0 && W == 1 && DCP_RS_PAIR_BIG))) void viterbi_rowsweep_kernel(dcp_scan_args a)
 {
     static_assert(!PF || STG > 0, "only staged variants prefetch two rows ahead");
+    static_assert(!TRACE || (STG == 0 && !PF), "the traceback's forward pass is an unstaged pair-mode kernel");
     static_assert(W == 1 || STG == 0, "only one-wavefront pairs stage rows");
     constexpr unsigned TASKS_PER_BLOCK = (W == 1 && STG == 0) ? 4u : 1u;
     constexpr int STAGED = STG;
@@ -842,6 +853,41 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
         RowOut o{ni, ni};
         unsigned j = 1;
         unsigned lane_boff = lane_off * 4u; // pinned in place by load_row's asm (by value it is copied per row)
+        // traceback: where this lane's values of the NEXT row go (row 0 is written here)
+        constexpr unsigned RW = 64u * R * W;
+        float *t_m = nullptr, *t_x = nullptr, *t_e = nullptr;
+        size_t t_mat = 0;
+        unsigned t_rows = 0;
+        if constexpr (TRACE)
+        {
+            float *const work = a.trace_work + a.trace_woff[task];
+            t_rows = L + 1u;
+            t_mat = (size_t)t_rows * RW;
+            t_m = work + node0;
+            float *const spec = work + 3u * t_mat; // N, B, E, J, C: [L + 1] each
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                t_m[r] = ni, t_m[t_mat + r] = ni, t_m[2u * t_mat + r] = ni;
+            t_m += RW;
+            // lanes 0, 1, 2 of the first wavefront hold N, J, C; lane 0 also writes B and E
+            t_x = spec + (x == 0u ? 0u : x == 1u ? 3u * t_rows : 4u * t_rows);
+            t_e = spec;
+            if ((W == 1 || wave == 0u) && lane < 3u) t_x[0] = ni;
+            if ((W == 1 || wave == 0u) && lane == 0u) t_e[t_rows] = 0.0f + xt[DCP_X_SB], t_e[2u * t_rows] = ni;
+            ++t_x, ++t_e;
+        }
+        auto const sink = [&](float const(&m_)[R], float const(&i_)[R], float const(&d_)[R], float E_, float X_, float B_) {
+            if constexpr (TRACE)
+            {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    t_m[r] = m_[r], t_m[t_mat + r] = i_[r], t_m[2u * t_mat + r] = d_[r];
+                t_m += RW;
+                if ((W == 1 || wave == 0u) && lane < 3u) *t_x = X_;
+                if ((W == 1 || wave == 0u) && lane == 0u) t_e[t_rows] = B_, t_e[2u * t_rows] = E_;
+                ++t_x, ++t_e;
+            }
+        };
         if constexpr (PF2)
         {
             // The rows that still come from global memory (the four- and five-base words) are fetched TWO DP rows
@@ -894,7 +940,7 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
         w = ((w << 2) | base_at(words, j)) & 1023u;                            \
         o = dp_row<R, W, PH>(s, t, em, em[2], em[3], em[4], eN, eI, sp, xEB, xc, wave, lane, gen, exact_e, [&]() { \
             load_row<R, STAGED>(em_base, ldk, lane_boff, eN_tab, eI_tab, w, em, em[2], em[3], em[4], eN, eI, stg, swd); \
-        });                                                                    \
+        }, sink);                                                              \
         ++j;                                                                   \
     }
         while (j + 4 <= L)
@@ -912,6 +958,11 @@ __global__ __launch_bounds__(rs_block_threads(R, W, STG, PF), rs_min_waves(R, W,
         float const C = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 2));
         float const nul = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.X), 3));
         float const alt = fmaxf(o.E + xt[DCP_X_ET], C + xt[DCP_X_CT]);
+        if constexpr (TRACE)
+        {
+            if (threadIdx.x == (W == 1 ? wave * 64u : 0u)) a.trace_alt[task] = alt;
+            continue;
+        }
         if (threadIdx.x == (W == 1 ? wave * 64u : 0u))
         {
             size_t const oi = (size_t)q * a.nprof_total + pm.pidx;
@@ -1419,7 +1470,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
 
     TraceView v;
     v.ldk = pm.ldk;
-    v.wd = pm.width;
+    v.wd = a.work_ld ? a.work_ld[h] : pm.width; // rows of the work matrices: 64 R W of the class after the row sweep's forward pass
     v.M = pm.core_size;
     v.L = a.seq_len[q];
     v.words = a.seq_words + a.seq_woff[q];
@@ -1485,6 +1536,10 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
     }
 
     // ---- forward -----------------------------------------------------------------
+    // (skipped when viterbi_rowsweep_kernel<..., TRACE> has filled the work area: dcp_gpu_trace_paths' default; this
+    // one-wavefront loop over rows in global memory is the tests' second implementation of it)
+    if (!a.skip_forward)
+    {
     // nodes per lane, contiguous; a one-wavefront profile's rows are not a multiple of 64 columns wide
     // (dcp_gpu_db_upload), so the last lanes may own fewer nodes or none
     unsigned const R = (ldk + 63u) / 64u;
@@ -1553,6 +1608,7 @@ __global__ __launch_bounds__(64) void viterbi_trace_kernel(dcp_trace_args a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();
+    }
     }
 
     // ---- backward (lane 0) ---------------------------------------------------------
@@ -1928,6 +1984,22 @@ extern "C" int dcp_launch_segsweep(int R, dcp_scan_args const *a, unsigned nbloc
     }
     DCP_CASE_G(5) DCP_CASE_G(6) DCP_CASE_G(7) DCP_CASE_G(8)
 #undef DCP_CASE_G
+    return -1;
+}
+
+// the traceback's forward pass over a->pairs: rows to a->trace_work (viterbi_rowsweep_kernel<R, W, 0, false, true>)
+extern "C" int dcp_launch_trace_forward(int R, int W, dcp_scan_args const *a, unsigned nblocks, void *stream)
+{
+#define DCP_CASE_T(r, w)                                                                                        \
+    if (R == r && W == w)                                                                                       \
+    {                                                                                                           \
+        hipLaunchKernelGGL((viterbi_rowsweep_kernel<r, w, 0, false, true>), dim3(nblocks), dim3(w == 1 ? 256u : 64u * w), 0, \
+                           (hipStream_t)stream, *a);                                                            \
+        return 0;                                                                                               \
+    }
+    DCP_CASE_T(1, 1) DCP_CASE_T(2, 1) DCP_CASE_T(3, 1) DCP_CASE_T(4, 1) DCP_CASE_T(5, 1) DCP_CASE_T(6, 1) DCP_CASE_T(7, 1)
+    DCP_CASE_T(8, 1) DCP_CASE_T(3, 4) DCP_CASE_T(4, 4) DCP_CASE_T(3, 8) DCP_CASE_T(4, 8) DCP_CASE_T(3, 16) DCP_CASE_T(4, 16)
+#undef DCP_CASE_T
     return -1;
 }
 

@@ -18,6 +18,19 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+/* scan_last_stats(): where the last scan_run_source spent its host time */
+static struct scan_stats g_stats;
+static double stat_now(void) { return omp_get_wtime(); }
+static void stat_add(double *field, double dt)
+{
+#pragma omp atomic
+    *field += dt;
+}
+void scan_last_stats(struct scan_stats *out)
+{
+    if (out) *out = g_stats;
+}
+
 #define fail dcp_host_fail
 
 /* ============================== products (src/server/prod.c) ================================== */
@@ -397,7 +410,10 @@ static enum rc batch_check(struct scan_thread *t, struct imm_seq const *seqs, un
 
 static enum rc batch_submit(struct scan_thread *t, int tid, struct imm_seq const *seqs, unsigned nseqs)
 {
+    double const t_in = stat_now();
     enum rc rc = thread_prepare(t, tid);
+    double const t_loaded = stat_now();
+    stat_add(&g_stats.load_s, t_loaded - t_in);
     if (rc) return rc;
     /* protein_profile_setup(pp, size, ...) rejects the empty sequence for every profile (:112) */
     size_t total = 0;
@@ -441,6 +457,7 @@ static enum rc batch_submit(struct scan_thread *t, int tid, struct imm_seq const
         prm.lrt_threshold = nextafterf(prm.lrt_threshold, -INFINITY);
     }
     if (!rc && (drc = dcp_gpu_scan(t->gpu, &prm))) rc = fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
+    stat_add(&g_stats.submit_s, stat_now() - t_loaded);
     return rc;
 }
 
@@ -448,7 +465,10 @@ static enum rc batch_trace(struct scan_thread *t, struct imm_seq const *seqs, un
                            struct batch_result *res)
 {
     memset(res, 0, sizeof *res);
+    double const t_in = stat_now();
     int drc = dcp_gpu_sync(t->gpu);
+    double const t_scanned = stat_now();
+    stat_add(&g_stats.scan_wait_s, t_scanned - t_in);
     if (drc) return fail((enum rc)drc, "failed to run viterbi: %s", dcp_gpu_last_error(t->gpu));
     /* the LRT filter ran on the device: only hits come back, sorted by (seq, profile) */
     enum rc rc = RC_OK;
@@ -475,11 +495,28 @@ static enum rc batch_trace(struct scan_thread *t, struct imm_seq const *seqs, un
                                           (unsigned)cap, res->soff, NULL)))
         rc = fail((enum rc)drc, "%s", dcp_gpu_last_error(t->gpu));
     if (rc) batch_result_free(res);
-    else res->nhits = nhits;
+    else
+    {
+        res->nhits = nhits;
+#pragma omp atomic
+        g_stats.hits += nhits;
+#pragma omp atomic
+        g_stats.steps += res->soff[nhits];
+    }
+    stat_add(&g_stats.trace_s, stat_now() - t_scanned);
     return rc;
 }
 
+static enum rc batch_rows_timed(struct scan_thread *t, struct imm_seq const *seqs, int64_t const *seq_ids, struct batch_result *res);
 static enum rc batch_rows(struct scan_thread *t, struct imm_seq const *seqs, int64_t const *seq_ids, struct batch_result *res)
+{
+    double const t_in = stat_now();
+    enum rc rc = batch_rows_timed(t, seqs, seq_ids, res);
+    stat_add(&g_stats.rows_s, stat_now() - t_in);
+    return rc;
+}
+
+static enum rc batch_rows_timed(struct scan_thread *t, struct imm_seq const *seqs, int64_t const *seq_ids, struct batch_result *res)
 {
     enum rc rc = RC_OK;
     unsigned const nhits = res->nhits;
@@ -638,6 +675,7 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
     unsigned const limit_n = batch + batch / 2u;
     unsigned long const limit_s = cfg.batch_symbols + cfg.batch_symbols / 2u;
     unsigned const qcap = limit_n + 1u;
+    memset(&g_stats, 0, sizeof g_stats);
     /* the partitions' host threads (one per device) each fan out once more: unpacking a partition and formatting a
      * batch's product rows are many-core jobs of their own */
     int const omp_levels = omp_get_max_active_levels();
@@ -790,6 +828,7 @@ enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned n
         memmove(qlen, qlen + nb, (size_t)(qn - nb) * sizeof *qlen);
         qn -= nb;
         enum rc shared = RC_OK;
+        ++g_stats.passes;
         if (nparts == 0) continue; /* an empty database: every sequence is consumed, nothing is scored */
         int const prev = cur ^ 1;
 #pragma omp parallel for schedule(static, 1) num_threads(nparts)

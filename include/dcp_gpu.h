@@ -310,6 +310,11 @@ int dcp_gpu_test_set_ring_stall(dcp_gpu_ctx *, int on);
 /* Same build only.  Cap in bytes on the boundary columns the segmented row sweep keeps per size class (0 restores the
  * default, 6 GiB): a small cap makes it sweep a class's queries chunk by chunk. */
 int dcp_gpu_test_set_seg_col_bytes(dcp_gpu_ctx *, unsigned long long bytes);
+/* Same build only.  own_forward != 0: dcp_gpu_trace_paths fills the hits' work areas with the trace kernel's own
+ * one-wavefront forward loop (rounds 1-3) instead of the row-sweep kernels' -- the tests' second implementation of
+ * the same rows; budget_floats != 0: floats of work area per round of launches (default 2^31), so that a handful of
+ * hits already takes several rounds. */
+int dcp_gpu_test_set_trace_mode(dcp_gpu_ctx *, int own_forward, unsigned long long budget_floats);
 /* Same build only.  Forces the grid-mode row-sweep kernel variant -- leading emission rows a block stages in
  * LDS (0, 20 or 84) and, in `block_waves`: bits 0..7 wavefronts per block (0: the default), bits 8..15 KiB of
  * unused LDS per block (an occupancy experiment), bit 16 the two-rows-ahead prefetch variant, bits 20..23 the
@@ -379,7 +384,10 @@ struct dcp_step
  * them. steps_out receives the paths back to back; step_off[nhits+1] their
  * offsets; alt_out (may be NULL) the log-likelihood the trace recomputed (equal
  * to the scan's). DCP_ENOMEM if cap_steps is too small (step_off[nhits] then
- * holds the needed total), DCP_EFAIL if a pair has no finite path. */
+ * holds the needed total), DCP_EFAIL if a pair has no finite path.
+ * Device work: the rows of every hit are swept once more by its size class's row-sweep kernel, which parks every
+ * row's M, I, D, N, B, E, J, C in a work area (12 x 64 R W + 20 bytes per row; at most 8 GiB per round of launches,
+ * kept by the context between calls), then one wavefront per hit walks back through it. */
 int dcp_gpu_trace_paths(dcp_gpu_ctx *, struct dcp_hit const *hits, unsigned nhits,
                         int multi_hits, int hmmer3_compat, int null_model,
                         struct dcp_step *steps_out, unsigned cap_steps, uint32_t *step_off,

@@ -872,6 +872,17 @@ struct scan_cfg
      * order. */
     unsigned long batch_symbols;
 };
+/* Where the last scan_run_source spent its time (not in the reference; profiles/host_scan_probe.c prints it): host
+ * seconds summed over the partitions' threads.  scan_wait_s is the wait for the device scans (the host has nothing
+ * else to do then); trace_s the hit fetch + the traceback of the hits' paths (device, the scan stream idle); rows_s the
+ * product rows (host; all but the last pass's run under the next pass's scan). */
+struct scan_stats
+{
+    unsigned passes;
+    unsigned long hits, steps;
+    double load_s, submit_s, scan_wait_s, trace_s, rows_s;
+};
+void scan_last_stats(struct scan_stats *out);
 void scan_resident_release(void);
 enum rc scan_run_source(char const *db_filename, struct scan_cfg cfg, unsigned num_threads,
                         scan_next_seq_func_t next_seq, void *arg);

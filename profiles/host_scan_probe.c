@@ -156,6 +156,11 @@ int main(int argc, char **argv)
                "end (file -> resident DB -> products), %ld product rows, %.1f seqs/s\n",
                job, job == 2 ? " (database resident from job 1)" : "", nseqs, len ? "fixed" : "100-10000", total_len, batch,
                batch_symbols, dt, cells / dt / 1e9, rows, nseqs / dt);
+        struct scan_stats ss;
+        scan_last_stats(&ss);
+        printf("    host seconds: load %.3f, submit (encode + upload + enqueue) %.3f, waiting for the scans %.3f, hit fetch + traceback %.3f, "
+               "product rows %.3f; %u passes, %lu hits, %lu path steps\n",
+               ss.load_s, ss.submit_s, ss.scan_wait_s, ss.trace_s, ss.rows_s, ss.passes, ss.hits, ss.steps);
     }
     scan_resident_release();
     remove(path);

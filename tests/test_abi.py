@@ -34,7 +34,7 @@ def test_test_hooks_are_not_in_the_shipped_library(dcp):
     -DDCP_TEST_HOOKS build, never in libdcp_hip.so or the host library."""
     hooks = declared_symbols(hooks=True)
     assert hooks == ["dcp_gpu_test_set_redo_cap", "dcp_gpu_test_set_ring_stall", "dcp_gpu_test_set_rowsweep_variant",
-                     "dcp_gpu_test_set_seg_col_bytes"]
+                     "dcp_gpu_test_set_seg_col_bytes", "dcp_gpu_test_set_trace_mode"]
     shipped = C.CDLL(dcp.LIB_PATH)
     assert not [h for h in hooks if hasattr(shipped, h)]
     host = os.path.join(os.path.dirname(dcp.LIB_PATH), "libdeciphon_host.so")

@@ -167,6 +167,69 @@ def test_trace_matches_oracle_paths(dcp, oracle32, multi, h3):
     assert hp == len(real_hits) >= 3
 
 
+@gpu
+@pytest.mark.parametrize("multi,h3", [(True, False), (False, False), (True, True)])
+def test_trace_forward_by_the_row_sweep_equals_the_trace_kernels_own(dcp, oracle32, multi, h3):
+    """dcp_gpu_trace_paths fills the hits' work areas with the row-sweep kernel of each profile's size class (round 4:
+    viterbi_rowsweep_kernel<R, W, 0, false, TRACE>, the scan's own rows) and walks back through them; the trace kernel's
+    own forward loop of rounds 1-3 is kept in the tests' build as a second implementation.  Both must give the same
+    steps and the same score for every pair: every size class (one to eight nodes per lane, four to sixteen
+    wavefronts per pair, the two classes whose profiles share table rows), a flagged (a few positive MD / DD) profile,
+    planted one- and two-domain queries, queries of 1 .. 9 nt (shorter than the five-row look-back), and a work budget
+    that cuts the hits into several rounds of launches; the order of the caller's hits is kept."""
+    import test_gpu_parity as tp
+
+    rng = np.random.default_rng(404 + int(multi) + 2 * int(h3))
+    sizes = [1, 3, 40, 64, 65, 128, 129, 192, 250, 300, 380, 448, 512, 520, 768, 900, 1100, 1536, 2049, 3000, 4096]
+    params = [tp.pfam_like_params(rng, M) for M in sizes]
+    # a flagged profile (finite MD / DD > 0 on a few nodes: the delete states enter E(j); with gains on every node a
+    # path collects score per delete and has no bounded optimum -- neither implementation traces that)
+    null, match, trans = tp.pfam_like_params(rng, 90)
+    trans = trans.copy()
+    trans[30:34, 2] = np.float32(0.05)
+    trans[31:34, 6] = np.float32(0.02)
+    params.append((null, match, trans))
+    sizes.append(90)
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    oprofs = {p: oracle32.new(*params[p], ENTRY_DIST_OCCUPANCY, 0.01) for p in (2, 6, 9, 13)}
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in (1, 2, 3, 4, 5, 6, 9)] + tp.rand_seqs(rng, 5, 20, 400)
+    seqs += [tp.planted_query(rng, oprofs[2], sizes[2], flank=5), tp.planted_query(rng, oprofs[6], sizes[6], flank=40),
+             tp.planted_query(rng, oprofs[13], sizes[13], flank=12),
+             np.concatenate([tp.planted_query(rng, oprofs[9], sizes[9]), tp.planted_query(rng, oprofs[9], sizes[9])])]
+    sc = dcp.Scanner(0, lib=dcp.load_testhooks())
+    try:
+        sc.upload_db(profiles, expand_on_host=True)
+        sc.upload_seqs(seqs)
+        sc.scan(multi, h3, 10.0)
+        nl, al = sc.scores()
+        pairs = [(q, p) for q in range(len(seqs)) for p in range(len(profiles)) if np.isfinite(al[q, p])]
+        order = rng.permutation(len(pairs))  # not in class order, not in sequence order
+        pairs = [pairs[i] for i in order]
+        hits = np.array([(q, p, nl[q, p], al[q, p]) for q, p in pairs], dcp.HIT_DTYPE)
+        assert len(hits) > 300
+        sc.test_set_trace_mode(0, 0)
+        new_paths, new_alt = sc.trace_paths(hits, multi, h3)
+        sc.test_set_trace_mode(0, 40 << 20)  # 160 MB of work area per round: the 4 096-node pairs take one round each
+        cut_paths, cut_alt = sc.trace_paths(hits, multi, h3)
+        sc.test_set_trace_mode(1, 0)
+        old_paths, old_alt = sc.trace_paths(hits, multi, h3)
+    finally:
+        sc.test_set_trace_mode(0, 0)
+        sc.close()
+    for (q, p), a, b, c_, x, y, z in zip(pairs, new_paths, cut_paths, old_paths, new_alt, cut_alt, old_alt):
+        assert x == al[q, p] and y == al[q, p] and z == al[q, p], (q, p)
+        assert np.array_equal(a, c_) and np.array_equal(b, c_), (q, p, sizes[p], len(seqs[q]))
+        assert int(a["seqlen"].sum()) == len(seqs[q])
+    # and against the oracle's own traceback for the planted pairs
+    for q, p in ((12, 2), (13, 6), (14, 13), (15, 9)):
+        i = pairs.index((q, p))
+        ll, want = oracle_path(oprofs[p], seqs[q], multi, h3)
+        got = [(int(s_["state_id"]), int(s_["seqlen"])) for s_ in new_paths[i]]
+        mine = oprofs[p].path_score(1, bytes(seqs[q]), got)
+        assert np.isfinite(mine) and abs(mine - ll) <= 2e-6 * abs(ll)
+
+
 def sc2_rows(dcp, profiles, seqs, hits, multi, h3):
     sc = dcp.Scanner(0)
     sc.upload_db(profiles, expand_on_host=True)
