@@ -15,7 +15,8 @@ queries of mixed lengths (1 nt .. a few kbp, now and then tens of kbp) with a fe
 
 All scans must give the same bits and the same hit list; a sample of pairs bounded by --oracle-cells (the long pairs
 are drawn with the same probability as the short ones) must equal the oracle's float32 recursion on the product's own
-tables, bit for bit.  The first difference prints the round's seed and shapes and exits 1; `--seed S --rounds 1`
+tables, bit for bit.  The round's hits (and a few other pairs) are traced back twice -- forward pass by the row-sweep
+kernels, and by the trace kernel's own loop -- and must give the same steps and the scan's score.  The first difference prints the round's seed and shapes and exits 1; `--seed S --rounds 1`
 replays a round.  One line per round; no file of the reference is read.
 """
 import argparse
@@ -140,10 +141,47 @@ def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool):
             hk.scan(multi, h3, 10.0, kernel=k)
             n, a = hk.scores()
             results[f"qlane{'2' if k == dcp.KERNEL_QLANE2 else ''}[redo cap {cap}, same variant]"] = (n.copy(), a.copy(), hk.hits().copy())
+        # traceback of the hits and of a few other pairs: the row-sweep kernels' forward pass (the shipped one) against
+        # the trace kernel's own loop, step for step, and the score the scan gave (a profile with gains on its delete
+        # transitions has no bounded best path: both must then refuse alike)
+        hk.test_set_rowsweep_variant(-1, 0)
+        hk.test_set_seg_col_bytes(0)
+        hk.test_set_redo_cap(0)
+        hk.scan(multi, h3, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
+        tn, ta = hk.scores()
+        cand = [(int(h["seq_idx"]), int(h["profile_idx"])) for h in hk.hits()[:24]]
+        fin = np.argwhere(np.isfinite(ta))
+        for i in rng.permutation(len(fin))[:8]:
+            cand.append((int(fin[i][0]), int(fin[i][1])))
+        cand = [(q, p) for q, p in cand if sizes[p] * len(seqs[q]) <= 4_000_000]
+        traced = 0
+        if cand:
+            th = np.array([(q, p, tn[q, p], ta[q, p]) for q, p in cand], dcp.HIT_DTYPE)
+            out = {}
+            for mode in (0, 1):
+                hk.test_set_trace_mode(mode, int(rng.choice([0, 0, 8 << 20])))
+                try:
+                    out[mode] = hk.trace_paths(th, multi, h3)
+                except dcp.DcpError as e:
+                    out[mode] = str(e)
+            hk.test_set_trace_mode(0, 0)
+            if isinstance(out[0], str) or isinstance(out[1], str):
+                if out[0] != out[1]:
+                    print(f"TRACE: the two forward passes fail differently: {out[0]!r} vs {out[1]!r}\n  {shape}", flush=True)
+                    return False, 0
+            else:
+                for (q, p), a0, a1, s0, s1 in zip(cand, out[0][0], out[1][0], out[0][1], out[1][1]):
+                    if not np.array_equal(a0, a1) or not (same_bits(s0, ta[q, p]) and same_bits(s1, ta[q, p])) \
+                            or int(a0["seqlen"].sum()) != len(seqs[q]):
+                        print(f"TRACE MISMATCH (query {q} len {len(seqs[q])}, profile {p} M {sizes[p]}): {len(a0)} vs {len(a1)} steps, "
+                              f"alt {s0!r} / {s1!r} / scan {ta[q, p]!r}\n  {shape}", flush=True)
+                        return False, 0
+                traced = len(cand)
     finally:
         hk.test_set_rowsweep_variant(-1, 0)
         hk.test_set_seg_col_bytes(0)
         hk.test_set_redo_cap(0)
+        hk.test_set_trace_mode(0, 0)
 
     rn, ra, rh = results["rowsweep"]
     for name, (n, a, h) in results.items():
@@ -197,7 +235,7 @@ def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool):
     if got != want:
         print(f"HIT LIST != LRT FILTER ({len(got)} vs {len(want)})\n  {shape}", flush=True)
         return False, 0
-    print(f"ok  {shape}; {len(results)} scans agree, {len(chosen)} pairs ({cells / 1e6:.1f} Mcell) == oracle, {len(rh)} hits, "
+    print(f"ok  {shape}; {len(results)} scans agree, {len(chosen)} pairs ({cells / 1e6:.1f} Mcell) == oracle, {len(rh)} hits, {traced} paths traced twice, "
           f"{list(results)[-1] if cap else list(results)[4]}", flush=True)
     return True, len(chosen)
 
