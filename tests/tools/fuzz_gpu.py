@@ -81,7 +81,7 @@ def same_bits(a, b):
     return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
 
 
-def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool):
+def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool, big_every=0):
     rng = np.random.default_rng(seed)
     nprof = int(rng.choice([1, 2, 3, 5, 8, 13, 24, 40]))
     big = rng.random() < 0.3
@@ -89,12 +89,18 @@ def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool):
     nq = int(rng.choice([1, 2, 5, 9, 21, 63, 64, 65, 100, 129, 200, 257, 400]))
     if sum(sizes) * nq > 3_000_000:  # keep a round's device work and the sample's spread in hand
         nq = max(1, 3_000_000 // sum(sizes))
+    if big_every and seed % big_every == 0:
+        # a round of many queries against few profiles: several 256-query blocks, slots holding several 64-query groups
+        # of very different lengths (the query-lane kernels' dynamic batching), redo lists that fill
+        nprof = int(rng.choice([1, 2, 4, 7]))
+        sizes = draw_sizes(rng, nprof, 700)
+        nq = int(rng.choice([513, 777, 1024, 1500, 2311]))
     entry = int(rng.choice([ENTRY_DIST_UNIFORM, ENTRY_DIST_OCCUPANCY]))
     eps = float(rng.choice([0.01, 0.05, 0.1]))
     cfg = dcp.ProteinCfg(entry, eps)
     params = [draw_params(rng, M) for M in sizes]
     profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
-    lens = draw_lengths(rng, nq, sum(sizes) < 3000)
+    lens = draw_lengths(rng, nq, sum(sizes) < 3000 and nq <= 400)
     seqs = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in lens]
     nplant = int(rng.integers(0, 4))
     for _ in range(nplant):
@@ -246,6 +252,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="stop after this many rounds (0: by --seconds)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--oracle-cells", type=float, default=6e7)
+    ap.add_argument("--big-every", type=int, default=7, help="every N-th seed draws 513 .. 2311 queries against 1 .. 7 profiles (0: never)")
     ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1))
     a = ap.parse_args()
     dcp = conftest.load_product()
@@ -257,7 +264,7 @@ def main():
     ok = True
     with ThreadPoolExecutor(a.threads) as pool:
         while ok and (a.rounds == 0 or rounds < a.rounds) and (a.rounds > 0 or time.time() - t0 < a.seconds):
-            ok, n = one_round(dcp, oracle32, sc, hk, a.seed + rounds, a.oracle_cells, pool)
+            ok, n = one_round(dcp, oracle32, sc, hk, a.seed + rounds, a.oracle_cells, pool, a.big_every)
             rounds += 1
             pairs += n
     sc.close()
