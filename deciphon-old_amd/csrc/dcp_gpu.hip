@@ -1510,8 +1510,14 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
         HIP_TRY(c, hipEventRecord(c->ev_start, c->stream)); // the forked streams wait for the counters' reset too
     }
     uint64_t seg_col_at = 0; // floats
-    for (int k = 0; k < kNumClasses; ++k)
+    for (int kk = 0; kk < kNumClasses; ++kk)
     {
+        // Forked launches (small batches): the classes of the largest profiles first.  A pair takes rows x the row's
+        // latency, which grows with the wavefronts the pair spans, and the few pairs of the largest classes, started
+        // last, ran on alone at the end: C3 DB, 1 / 2 / 4 / 16 queries 10.3 / 16.8 / 26.5 / 74.2 -> 9.4 / 15.4 / 25.2 /
+        // 70.8 ms; C5 DB 4 .. 32 queries 1-5 % less, 1 and 64 queries 1-2 % more (profiles/r04/class_launch_order.txt;
+        // the chip-filling classes first and only then the sparse ones, or the sparse ones first: in between)
+        int const k = overlap ? kNumClasses - 1 - kk : kk;
         unsigned first = c->class_first[k], last = c->class_first[k + 1];
         if (last <= first) continue;
         hipStream_t const ls = overlap ? c->class_stream[k] : c->stream;
