@@ -191,6 +191,7 @@ struct dcp_gpu_ctx
     // small row-sweep scans (the reference's one-sequence-at-a-time mode) are bound by the latency
     // of one pair's row chain, not by throughput: their size-class launches run side by side
     hipStream_t class_stream[kNumClasses] = {nullptr};
+    hipEvent_t ev_trace[kNumClasses + 1] = {nullptr}; // traceback: the fork point and one event per class's forward launch
     bool last_overlapped = false;
     int launched_class[kMaxLaunches] = {0};
     bool launched_redo[kMaxLaunches] = {false}; // the exact kernel behind a segmented sweep: its cells are counted there
@@ -293,6 +294,8 @@ void dcp_gpu_ctx_del(dcp_gpu_ctx *c)
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (int k = 0; k < dcp_gpu_ctx::kMaxLaunches; ++k)
         if (c->ev_class[k]) (void)hipEventDestroy(c->ev_class[k]);
+    for (int k = 0; k <= kNumClasses; ++k)
+        if (c->ev_trace[k]) (void)hipEventDestroy(c->ev_trace[k]);
     for (int k = 0; k < kNumClasses; ++k)
         if (c->class_stream[k]) (void)hipStreamDestroy(c->class_stream[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1933,10 +1936,18 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
             fa.qchunk = 1u;
             fa.nchunks = c->nseqs;
             fa.trace_work = c->d_trace_work.p;
-            for (int k = 0; k < kNumClasses; ++k)
+            // the classes' launches side by side on their own streams, largest profiles first: a class's launch lasts as
+            // long as its longest hit and seldom fills the chip (one after the other they took 0.31 of a job's 0.40 s of
+            // traceback, profiles/r04/host_scan_probe_mixed_kernel_stats.csv)
+            for (int k = 0; k <= kNumClasses; ++k)
+                if (!c->ev_trace[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_trace[k], hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->ev_trace[kNumClasses], c->stream));
+            for (int k = kNumClasses - 1; k >= 0; --k)
             {
                 if (counts[k] == 0u) continue;
                 SizeClass const sc = kClasses[k];
+                hipStream_t const ls = c->class_stream[k];
+                HIP_TRY(c, hipStreamWaitEvent(ls, c->ev_trace[kNumClasses], 0));
                 fa.pairs = d_pairs.p + cfirst[k];
                 fa.npairs = d_counts.p + k;
                 fa.pair_cap = counts[k];
@@ -1944,8 +1955,10 @@ int dcp_gpu_trace_paths(dcp_gpu_ctx *c, struct dcp_hit const *hits, unsigned nhi
                 fa.trace_alt = d_alt.p + cfirst[k];
                 unsigned const tpb = dcp_rowsweep_tasks_per_block(sc.W);
                 unsigned const nb = ((counts[k] + tpb - 1u) / tpb + 7u) / 8u * 8u;
-                if (dcp_launch_trace_forward(sc.R, sc.W, &fa, nb, c->stream))
+                if (dcp_launch_trace_forward(sc.R, sc.W, &fa, nb, ls))
                     return c->fail(DCP_EFAIL, "no traceback kernel for class R=%d W=%d", sc.R, sc.W);
+                HIP_TRY(c, hipEventRecord(c->ev_trace[k], ls));
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_trace[k], 0));
             }
             HIP_TRY(c, hipGetLastError());
         }
