@@ -1466,8 +1466,10 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     c->redo_pending = false;
     c->last_redo_pairs = 0;
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    // fork / join around the class launches when no single one fills the chip
-    bool const overlap = (uint64_t)nq * c->nprof < ((uint64_t)1 << 21);
+    // fork / join around the class launches when no single one fills the chip for long (2^22 pairs: 20 000 profiles x 209
+    // queries, i.e. every batch the automatic choice gives the row sweep; 112 .. 160 queries: 1 % faster than one launch
+    // after the other, profiles/r04/class_launch_order.txt)
+    bool const overlap = (uint64_t)nq * c->nprof < ((uint64_t)1 << 22);
     c->last_overlapped = overlap;
     // Multi-wavefront classes with a segmented-sweep kernel (dcp_kernels.hip): one wavefront per pair, one SEGMENT of
     // the profile per launch, B(j) = N(j) + NB, the pairs with feedback finished by the exact kernel behind it.
