@@ -639,6 +639,9 @@ def main():
     ap.add_argument("--as-rank", default="", metavar="R/N",
                     help="one-GPU rehearsal of an N-GPU run's rank R: this GPU holds shard R of N of the DB and scans the "
                          "N x larger query step an N-GPU run uses (value = this one rank's rate; --gpus 1 only)")
+    ap.add_argument("--one-layout", action="store_true",
+                    help="DCP_DB_ONE_LAYOUT: only the row-sweep tables resident, the query-lane kernels gather their tile "
+                         "images from them (half the DB's footprint; not the default, not the headline line)")
     ap.add_argument("--stub-scan", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU (gloo)
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--stub-sleep", type=float, default=0.0, help=argparse.SUPPRESS)  # seconds per stub step
@@ -711,7 +714,8 @@ def main():
     t_build = time.perf_counter() - t0
     sc = dcp.Scanner(local_rank)
     t0 = time.perf_counter()
-    sc.upload_db(profiles)
+    sc.upload_db(profiles, one_layout=args.one_layout)
+    db_tables = {"one_layout": bool(sc.one_layout), "table_bytes_after_upload": int(sc.table_bytes)}
     t_upload = time.perf_counter() - t0
     del profiles
 
@@ -926,7 +930,7 @@ def main():
                 "workload": f"{wl['label']}: {nprof} sampled profiles (sum M={int(sizes.sum())}, mean {sizes.mean():.0f}), "
                             f"{qstep} distinct {str(qlen) + '-nt' if qlen else '100-10000-nt'} queries per step, multi_hits, lrt>=10",
                 "profiles_per_gpu": e - b, "queries_per_step": qstep, "query_len": qlen,
-                "kernel": args.kernel,
+                "kernel": args.kernel, "one_table_layout": bool(args.one_layout),
                 "dense_families": args.dense or None, "dense_queries": (None if not args.dense else
                                                                          "random" if args.dense_random else "consensus"),
                 "parallelism": f"profile-shard x{world}" + (f", RCCL hit gather per step ({cdist_state['kind']})" if (world > 1 or force_dist) else ""),
@@ -939,6 +943,7 @@ def main():
             "e2e": e2e,
             "small_batches": small,
             "setup_s": {"profile_build": round(t_build, 1), "db_upload_expand": round(t_upload, 1)},
+            "db_tables": dict(db_tables, table_bytes_at_end=int(sc.table_bytes)),
             # every DCP_* variable in the environment (the library reads none of them; bench.py reads
             # DCP_BENCH_FORCE_DIST only)
             "env_dcp": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DCP_")},

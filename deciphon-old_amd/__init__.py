@@ -57,6 +57,7 @@ ABI_SYMBOLS = [
     "dcp_lrt", "dcp_partition_by_count", "dcp_partition_by_cells", "dcp_gpu_device_count",
     "dcp_gpu_ctx_new", "dcp_gpu_ctx_del", "dcp_gpu_last_error", "dcp_gpu_stream",
     "dcp_gpu_db_upload", "dcp_gpu_db_nprofiles", "dcp_gpu_db_fetch_match_table",
+    "dcp_gpu_db_one_layout", "dcp_gpu_db_table_bytes",
     "dcp_gpu_seqs_upload", "dcp_gpu_seqs_upload_text", "dcp_gpu_nseqs", "dcp_gpu_scan",
     "dcp_gpu_sync", "dcp_gpu_last_scan_kernel", "dcp_gpu_hit_buffer", "dcp_gpu_last_scan_redo_pairs", "dcp_gpu_last_scan_ms", "dcp_gpu_last_scan_launches", "dcp_gpu_fetch_scores",
     "dcp_gpu_fetch_hits", "dcp_gpu_scan_range", "dcp_gpu_set_hit_buffer",
@@ -88,6 +89,7 @@ class ScanParams(C.Structure):
 
 
 KERNEL_AUTO, KERNEL_ROWSWEEP, KERNEL_QLANE, KERNEL_QLANE2 = 0, 1, 2, 3
+DB_EXPAND_ON_HOST, DB_ONE_LAYOUT = 1, 2  # dcp_gpu_db_upload flags (include/dcp_gpu.h)
 
 
 class Hit(C.Structure):
@@ -135,6 +137,8 @@ def _load(path=None, hooks=False):
         "dcp_gpu_stream": (P, [P]),
         "dcp_gpu_db_upload": (I, [P, P, U, I]),
         "dcp_gpu_db_nprofiles": (U, [P]),
+        "dcp_gpu_db_one_layout": (I, [P]),
+        "dcp_gpu_db_table_bytes": (C.c_uint64, [P]),
         "dcp_gpu_db_fetch_match_table": (I, [P, U, P]),
         "dcp_gpu_seqs_upload": (I, [P, P, P, U]),
         "dcp_gpu_seqs_upload_text": (I, [P, C.c_char_p, P, U]),
@@ -491,10 +495,20 @@ class Scanner:
     def stream(self):
         return self._lib.dcp_gpu_stream(self._c)
 
-    def upload_db(self, profiles, expand_on_host=False):
+    def upload_db(self, profiles, expand_on_host=False, one_layout=False):
+        """one_layout: DCP_DB_ONE_LAYOUT (include/dcp_gpu.h) -- no tile images, the query-lane kernels gather them."""
         arr = (C.c_void_p * len(profiles))(*[p._h for p in profiles])
-        self._check(self._lib.dcp_gpu_db_upload(self._c, arr, len(profiles), int(expand_on_host)))
+        flags = (DB_EXPAND_ON_HOST if expand_on_host else 0) | (DB_ONE_LAYOUT if one_layout else 0)
+        self._check(self._lib.dcp_gpu_db_upload(self._c, arr, len(profiles), flags))
         self._profiles = list(profiles)
+
+    @property
+    def one_layout(self):
+        return bool(self._lib.dcp_gpu_db_one_layout(self._c))
+
+    @property
+    def table_bytes(self):
+        return int(self._lib.dcp_gpu_db_table_bytes(self._c))
 
     @property
     def nprofiles(self):

@@ -114,6 +114,9 @@ struct dcp_gpu_ctx
     std::vector<dcp_expand_tile> rs_tiles;
     uint64_t rs_floats = 0;
     bool rs_ready = false;
+    // DCP_DB_ONE_LAYOUT: no tile images; the query-lane kernels gather a tile's LDS image from d_emis_match (always resident)
+    bool one_layout = false;
+    uint64_t table_bytes = 0; // expanded match tables resident after the upload (either or both layouts)
     // query-lane kernel layout (dcp_qlane.hip)
     int ql_G = 2; // nodes per tile = 4 * G (KT = 8: the tile transitions fit in SGPRs)
     std::vector<dcp_ql_prof> ql_metas; // same order as metas
@@ -375,9 +378,11 @@ struct StagedUpload
 // DB upload
 // ---------------------------------------------------------------------------
 int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
-                      unsigned nprofiles, int expand_on_host)
+                      unsigned nprofiles, int flags)
 {
     if (!c) return DCP_EINVAL;
+    if (flags & ~(DCP_DB_EXPAND_ON_HOST | DCP_DB_ONE_LAYOUT)) return c->fail(DCP_EINVAL, "unknown upload flags %d", flags);
+    int const expand_on_host = flags & DCP_DB_EXPAND_ON_HOST;
     if (!profiles || nprofiles == 0) return c->fail(DCP_EINVAL, "empty profile list");
     if (nprofiles > (1u << 20)) return c->fail(DCP_EINVAL, "too many profiles"); // MAX_NPROFILES limits.h:7
     HIP_TRY(c, hipSetDevice(c->device));
@@ -521,9 +526,28 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
     c->rs_ready = false;
     c->rs_tiles.clear();
     c->d_emis_match.release();
+    c->d_emis_tiles.release();
     c->d_dists.release();
     c->d_eps.release();
-    if (expand_on_host) HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
+    // One table layout or two.  The tile images of the query-lane kernels (19.6 GB for 20 000 Pfam-like profiles) repeat
+    // the numbers of the row-sweep tables (20.6 GB), which a scan with hits needs anyway (redo lists, traceback).  With
+    // DCP_DB_ONE_LAYOUT -- or by itself when both would not leave 16 GiB of this device's free memory for planes,
+    // sequences and the traceback's work areas -- only the row-sweep tables are built, at once, and the query-lane
+    // kernels gather each tile's image from them (stage_tile_image<G, true>, dcp_qlane.hip).
+    uint64_t tile_floats_needed = 0;
+    for (unsigned i = 0; i < nprofiles; ++i)
+        tile_floats_needed += (uint64_t)((c->metas[i].core_size + 4u * (unsigned)c->ql_G - 1u) / (4u * (unsigned)c->ql_G)) *
+                              (4u * (unsigned)c->ql_G) * DCP_NCODES;
+    c->one_layout = (flags & DCP_DB_ONE_LAYOUT) != 0;
+    if (!c->one_layout)
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        uint64_t const both = (tile_floats_needed + emis_floats + (match_rows + 2ull * nprofiles) * (DCP_NDIST + 1)) * sizeof(float);
+        if (both + (16ull << 30) > (uint64_t)free_b) c->one_layout = true;
+    }
+    c->table_bytes = (c->one_layout ? emis_floats : tile_floats_needed + (expand_on_host ? emis_floats : 0)) * sizeof(float);
+    if (expand_on_host || c->one_layout) HIP_TRY(c, c->d_emis_match.alloc(emis_floats));
     HIP_TRY(c, c->d_trans8.alloc(trans_floats));
     HIP_TRY(c, c->d_emis_insert.alloc((size_t)nprofiles * DCP_NCODES));
     HIP_TRY(c, c->d_emis_null.alloc((size_t)nprofiles * DCP_NCODES));
@@ -575,14 +599,15 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         c->max_tiles = std::max(c->max_tiles, qm.ntiles);
         qm.needs_exact_e = (m.flags & DCP_PROF_EXACT_E) ? 1u : 0u;
         c->any_exact_e = c->any_exact_e || qm.needs_exact_e != 0u;
-        qm.tile_off = tile_floats;
+        qm.tile_off = c->one_layout ? m.emis_off : tile_floats; // one layout: its first column in emis_match
+        qm.ldk = c->one_layout ? m.ldk : 0u;
         qm.ttrans_off = (uint32_t)ttrans_floats;
         tile_floats += (uint64_t)qm.ntiles * KT * DCP_NCODES;
         ttrans_floats += (uint64_t)qm.ntiles * (KT + 1) * 8;
     }
     if (ttrans_floats > 0xffffffffull) return c->fail(DCP_EINVAL, "DB too large for 32-bit transition offsets");
     HIP_TRY(c, c->d_ql_metas.alloc(nprofiles));
-    HIP_TRY(c, c->d_emis_tiles.alloc(tile_floats));
+    if (!c->one_layout) HIP_TRY(c, c->d_emis_tiles.alloc(tile_floats));
     HIP_TRY(c, c->d_ttrans.alloc(ttrans_floats));
     HIP_TRY(c, hipMemcpy(c->d_ql_metas.p, c->ql_metas.data(), nprofiles * sizeof(dcp_ql_prof), hipMemcpyHostToDevice));
     {
@@ -637,8 +662,9 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             // to the device in one piece below (this path is the tests': small databases)
             for (unsigned code = 0; code < DCP_NCODES; ++code)
                 std::memcpy(&emis_host[m.emis_off + (size_t)code * m.ldk], &tab[(size_t)code * m.width], sizeof(float) * m.width);
-            HIP_TRY(c, hipMemcpy(c->d_emis_tiles.p + qm.tile_off, img.data(), img.size() * sizeof(float),
-                                 hipMemcpyHostToDevice));
+            if (!c->one_layout)
+                HIP_TRY(c, hipMemcpy(c->d_emis_tiles.p + qm.tile_off, img.data(), img.size() * sizeof(float),
+                                     hipMemcpyHostToDevice));
             dcp_frame_table_host(dcp_profile_insert_dist(pr), eps, &ins[(size_t)m.pidx * DCP_NCODES]);
             dcp_frame_table_host(dcp_profile_null_dist(pr), eps, &nul[(size_t)m.pidx * DCP_NCODES]);
         }
@@ -692,7 +718,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
             }
         }
         size_t const n_match_tiles = tiles.size();
-        for (unsigned i = 0; i < nprofiles; ++i)
+        for (unsigned i = 0; i < nprofiles && !c->one_layout; ++i)
         {
             dcp_prof_meta const &m = c->metas[i];
             dcp_ql_prof const &qm = c->ql_metas[i];
@@ -731,9 +757,19 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * sizeof(dcp_expand_tile), hipMemcpyHostToDevice));
         c->rs_tiles.assign(tiles.begin(), tiles.begin() + (long)n_match_tiles);
         dcp_expand_args ea{d_tiles.p, d_dists.p, d_eps.p, nullptr};
-        ea.tiles = d_tiles.p + n_match_tiles;
-        ea.out = c->d_emis_tiles.p;
-        dcp_launch_expand(&ea, (unsigned)n_image_tiles, c->stream);
+        if (c->one_layout)
+        {
+            // the row-sweep tables now, not on first use
+            ea.tiles = d_tiles.p;
+            ea.out = c->d_emis_match.p;
+            dcp_launch_expand(&ea, (unsigned)n_match_tiles, c->stream);
+        }
+        else
+        {
+            ea.tiles = d_tiles.p + n_match_tiles;
+            ea.out = c->d_emis_tiles.p;
+            dcp_launch_expand(&ea, (unsigned)n_image_tiles, c->stream);
+        }
         ea.tiles = d_tiles.p + n_match_tiles + n_image_tiles;
         ea.out = c->d_emis_insert.p;
         dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
@@ -742,6 +778,13 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         dcp_launch_expand(&ea, (unsigned)n_special_tiles, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->one_layout)
+        {
+            // nothing is rebuilt later: the compact dists go
+            c->rs_tiles.clear();
+            c->d_dists.release();
+            c->d_eps.release();
+        }
     }
     // the grouped profiles' descriptors and their merged {insert, background} tables
     if (!c->mp_groups.empty())
@@ -754,7 +797,7 @@ int dcp_gpu_db_upload(dcp_gpu_ctx *c, dcp_profile *const *profiles,
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    c->rs_ready = expand_on_host != 0;
+    c->rs_ready = expand_on_host != 0 || c->one_layout;
     c->nprof = nprofiles;
     return DCP_OK;
 }
@@ -774,6 +817,15 @@ static int ensure_rowsweep_layout(dcp_gpu_ctx *c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->rs_ready = true;
     return DCP_OK;
+}
+
+int dcp_gpu_db_one_layout(dcp_gpu_ctx const *c) { return c && c->one_layout ? 1 : 0; }
+uint64_t dcp_gpu_db_table_bytes(dcp_gpu_ctx const *c)
+{
+    if (!c || c->nprof == 0) return 0;
+    // the lazily expanded row-sweep tables count once they are there
+    bool const lazy_there = !c->one_layout && c->rs_ready && c->d_dists.p;
+    return c->table_bytes + (lazy_there ? c->rs_floats * sizeof(float) : 0);
 }
 
 int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *c, unsigned p, float *out)
@@ -1350,7 +1402,8 @@ int dcp_gpu_scan_range(dcp_gpu_ctx *c, struct dcp_scan_params const *prm, unsign
     {
         dcp_qlane_args qa{};
         qa.profs = c->d_ql_metas.p;
-        qa.emis_tiles = c->d_emis_tiles.p;
+        qa.emis_tiles = c->one_layout ? c->d_emis_match.p : c->d_emis_tiles.p;
+        qa.tiles_from_rows = c->one_layout ? 1u : 0u;
         qa.emis_insert = c->d_emis_insert.p;
         qa.emis_null = c->d_emis_null.p;
         qa.ttrans = c->d_ttrans.p;

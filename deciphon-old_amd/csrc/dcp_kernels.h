@@ -152,6 +152,7 @@ struct dcp_ql_prof
     uint32_t rs_slot;    // this profile's entry in the row-sweep kernel's profs[]
     uint32_t cls;        // its row-sweep size class (redo list to append to)
     uint32_t needs_exact_e; // a finite MD or DD > 0: E(j) is not the match states' maximum -> row sweep (redo lists)
+    uint32_t ldk;        // DCP_DB_ONE_LAYOUT: row length of its row-sweep table (tile_off = its first column in emis_match)
 };
 
 // A group = up to 64 queries, consecutive in the length order, that ONE wavefront sweeps together (one lane each).
@@ -170,7 +171,7 @@ struct dcp_ql_group
 struct dcp_qlane_args
 {
     dcp_ql_prof const *profs; // sorted by ascending size
-    float const *emis_tiles;  // per profile [T][G][1364][4]: the LDS image of each tile
+    float const *emis_tiles;  // per profile [T][G][1364][4]: the LDS image of each tile (tiles_from_rows: emis_match)
     float const *emis_insert; // [nprof_total][1364]
     float const *emis_null;   // [nprof_total][1364]
     float const *ttrans;      // per profile [T][KT+1][8] (row KT = edges into the next tile)
@@ -213,6 +214,7 @@ struct dcp_qlane_args
     unsigned plane_rows; // rows of a block's scratch planes: the longest slot's rows + 8 (prefetch runs past the end)
     unsigned ntasks;   // nprof * nqblocks
     unsigned nqblocks; // blocks of query slots
+    unsigned tiles_from_rows; // DCP_DB_ONE_LAYOUT: the launchers take the kernels that gather a tile's image from emis_match
 };
 
 struct dcp_expand_args

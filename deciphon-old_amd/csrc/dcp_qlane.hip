@@ -168,6 +168,40 @@ struct RowIn
 // shorter than loaded-HBM latency, and with two waves per SIMD a late load stalls
 // the SIMD.
 // scratch plane access: wave-uniform base pointer + 32-bit BYTE offset, the form that maps to
+// A tile's LDS image [G][1364 codes][4 nodes].  ROWS = false: a contiguous copy from emis_tiles (the DB holds both table
+// layouts).  ROWS = true (DCP_DB_ONE_LAYOUT: only the row-sweep tables [1364][ldk] are resident, half the
+// footprint): a.emis_tiles is emis_match, pm.tile_off the profile's first column there, and entry (group, code) is the
+// 16 aligned bytes at row `code`, columns 8 t + 4 group .. + 3 -- inside the profile's own columns whenever the group's
+// first node exists (a row ends in >= 1 column of -inf rounded up to 4; the columns behind core_size are -inf there as
+// they are in the image); a group past the last node is -inf.  One strided 16-byte load per entry instead of a
+// coalesced one: 2 728 per tile and block, against the ~10^6 cells the block then sweeps on it.
+template <int G, bool ROWS>
+__device__ __forceinline__ void stage_tile_image(float *tabM, dcp_qlane_args const &a, dcp_ql_prof const &pm, unsigned t,
+                                                 unsigned first, unsigned stride)
+{
+    constexpr unsigned N4 = (unsigned)(G * NC);
+    float4 *dst = reinterpret_cast<float4 *>(tabM);
+    if constexpr (!ROWS)
+    {
+        float4 const *__restrict__ src = reinterpret_cast<float4 const *>(a.emis_tiles + pm.tile_off + (size_t)t * (N4 * 4u));
+        for (unsigned i = first; i < N4; i += stride)
+            dst[i] = src[i];
+    }
+    else
+    {
+        float const *__restrict__ rows = a.emis_tiles + pm.tile_off + t * (4u * (unsigned)G);
+        unsigned const ldk = pm.ldk, M = pm.core_size;
+        for (unsigned i = first; i < N4; i += stride)
+        {
+            unsigned const grp = i / (unsigned)NC, code = i - grp * (unsigned)NC;
+            float4 v = make_float4(ninf(), ninf(), ninf(), ninf());
+            if (t * (4u * (unsigned)G) + grp * 4u < M)
+                v = *reinterpret_cast<float4 const *>(rows + (size_t)code * ldk + grp * 4u);
+            dst[i] = v;
+        }
+    }
+}
+
 // global_load/store with an SGPR base and a VGPR offset (no 64-bit address arithmetic per access)
 __device__ __forceinline__ float ld_off(float const *base, unsigned boff)
 {
@@ -937,7 +971,7 @@ __device__ __forceinline__ void ql_publish(dcp_qlane_args const &a, dcp_ql_prof 
 
 } // namespace
 
-template <int G, int NT, int D>
+template <int G, int NT, int D, bool ROWS = false>
 __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_args a)
 {
     constexpr int KT = 4 * G;
@@ -983,13 +1017,7 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
         for (unsigned t = 0; t < T; ++t)
         {
             __syncthreads(); // previous tile's readers are done with tabM
-            {
-                float4 const *__restrict__ src = reinterpret_cast<float4 const *>(
-                    a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
-                float4 *dst = reinterpret_cast<float4 *>(tabM);
-                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
-                    dst[i] = src[i];
-            }
+            stage_tile_image<G, ROWS>(tabM, a, pm, t, tid, (unsigned)NT);
             __syncthreads();
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
@@ -1038,12 +1066,11 @@ __global__ __launch_bounds__(NT, NT / 128) void viterbi_qlane_kernel(dcp_qlane_a
 // Measured motive (profiles/r02/diag_builds.txt): with the planes collapsed to one row (no HBM traffic)
 // the single-stage kernel runs 26 % faster, with every other boundary collapsed 12 % faster.
 // ---------------------------------------------------------------------------------------------------
-template <int G, int D>
+template <int G, int D, bool ROWS = false>
 __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a)
 {
     constexpr int NT = (int)kRLanes; // lanes per stage
     constexpr int KT = 4 * G;
-    constexpr int TAB_FLOATS = G * NC * 4;
     __shared__ __attribute__((aligned(16))) float lds[kL2Bytes / 4u]; // the kernel's only LDS object: at address 0
     // Stage 0 = wavefronts 0-3, stage 1 = wavefronts 4-7; wavefront w of stage 1 holds the same 64 queries as
     // wavefront w of stage 0.  (The other map -- even / odd wavefronts -- measured 0.6 % slower.)
@@ -1116,14 +1143,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
             unsigned const t = 2u * st + stage;
             bool const mine = t < T; // the last step of an odd profile has no odd tile
             __syncthreads();       // previous step: both stages are done with their images and with the ring
-            if (mine)
-            {
-                float4 const *__restrict__ src =
-                    reinterpret_cast<float4 const *>(a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
-                float4 *dst = reinterpret_cast<float4 *>(tabM);
-                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
-                    dst[i] = src[i];
-            }
+            if (mine) stage_tile_image<G, ROWS>(tabM, a, pm, t, tid, (unsigned)NT);
             flag_store((lds_uint *)(lk.base + lk.my_flag + tid * 4u), 0u); // row counters restart with every step
             __syncthreads();
             // (the scan has failed -- some wavefront's hand-shake ran into its bound: no more sweeps, the task winds down)
@@ -1199,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void viterbi_qlane2_kernel(dcp_qlane_args a
 // The slices' bases are not compile-time constants of the row code, so each gather address pays one add
 // (+10 VALU per row, 4 %).  Same rows (ql_row), same results.
 // ---------------------------------------------------------------------------------------------------
-template <int G, int D>
+template <int G, int D, bool ROWS = false>
 __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args a)
 {
     constexpr int NT = 64;
@@ -1238,13 +1258,7 @@ __global__ __launch_bounds__(192, 1) void viterbi_qlane_w3_kernel(dcp_qlane_args
         bool t_loaded = false;
         for (unsigned t = 0; t < T; ++t)
         {
-            {
-                float4 const *__restrict__ src =
-                    reinterpret_cast<float4 const *>(a.emis_tiles + pm.tile_off + (size_t)t * TAB_FLOATS);
-                float4 *dst = reinterpret_cast<float4 *>(tabM);
-                for (unsigned i = tid; i < (unsigned)(TAB_FLOATS / 4); i += (unsigned)NT)
-                    dst[i] = src[i];
-            }
+            stage_tile_image<G, ROWS>(tabM, a, pm, t, tid, (unsigned)NT);
             compiler_fence(); // the sweep's gathers stay behind the image's stores (same wavefront: LDS keeps the order)
             cfloat *tt = as_const(a.ttrans + pm.ttrans_off + (size_t)t * (KT + 1) * 8);
             bool const first = t == 0, last = t + 1 == T;
@@ -1316,10 +1330,13 @@ __global__ __launch_bounds__(NT) void transpose_words_kernel(dcp_qlane_args a)
         dst[r * (unsigned)NT + tid] = 0;
 }
 
+// (dcp_qlane_args::tiles_from_rows picks the ROWS instantiation: the default kernels' code is the same with and
+// without it in the library)
 template <int G, int NT, int D>
 static void launch_ql(dcp_qlane_args const *a, unsigned nblocks, hipStream_t s)
 {
-    hipLaunchKernelGGL((viterbi_qlane_kernel<G, NT, D>), dim3(nblocks), dim3(NT), 0, s, *a);
+    if (a->tiles_from_rows) hipLaunchKernelGGL((viterbi_qlane_kernel<G, NT, D, true>), dim3(nblocks), dim3(NT), 0, s, *a);
+    else hipLaunchKernelGGL((viterbi_qlane_kernel<G, NT, D>), dim3(nblocks), dim3(NT), 0, s, *a);
 }
 
 // One configuration is built: KT = 8 nodes per tile (G = 2: the tile's transitions fit in
@@ -1356,13 +1373,17 @@ extern "C" unsigned dcp_qlane2_lds_bytes(void) { return kL2Bytes; }
 // three independent 64-query wavefronts per block (small batches): nblocks blocks of 192 threads
 extern "C" int dcp_launch_qlane_w3(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    hipLaunchKernelGGL((viterbi_qlane_w3_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(192), 0, (hipStream_t)stream, *a);
+    if (a->tiles_from_rows)
+        hipLaunchKernelGGL((viterbi_qlane_w3_kernel<2, DCP_QLANE_D, true>), dim3(nblocks), dim3(192), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((viterbi_qlane_w3_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(192), 0, (hipStream_t)stream, *a);
     return 0;
 }
 
 extern "C" int dcp_launch_qlane2(dcp_qlane_args const *a, unsigned nblocks, void *stream)
 {
-    hipLaunchKernelGGL((viterbi_qlane2_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, *a);
+    if (a->tiles_from_rows)
+        hipLaunchKernelGGL((viterbi_qlane2_kernel<2, DCP_QLANE_D, true>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((viterbi_qlane2_kernel<2, DCP_QLANE_D>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, *a);
     return 0;
 }
 

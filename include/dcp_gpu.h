@@ -229,12 +229,30 @@ char const *dcp_gpu_last_error(dcp_gpu_ctx const *);
 void *dcp_gpu_stream(dcp_gpu_ctx *);
 
 /* Upload `nprofiles` profiles; expands every match/insert/null frame-state
- * emission table into HBM (layout: DESIGN.md §3). expand_on_host != 0 computes
- * the tables with dcp_frame_table_host and copies them (slow; parity tests).
- * Replaces any previously uploaded DB. */
+ * emission table into HBM (layout: DESIGN.md §3).  `flags` (0 for a server):
+ *   DCP_DB_EXPAND_ON_HOST  the tables are computed with dcp_frame_table_host and
+ *                          copied (slow; parity tests).  (The argument used to be
+ *                          `int expand_on_host`: 0 / 1 keep their meaning.)
+ *   DCP_DB_ONE_LAYOUT      keep ONE layout of the match tables resident -- the row
+ *                          sweep's [1364][ldk] -- and let the query-lane kernels
+ *                          gather their 8-node tile images from it, instead of
+ *                          holding those images as a second copy: half the
+ *                          footprint (20.6 instead of 40.2 GB per 20 000 Pfam-like
+ *                          profiles), same bits.  Chosen by the library itself when
+ *                          both layouts would not leave 16 GiB of the device's
+ *                          free memory.
+ * Replaces any previously uploaded DB.  (The reference re-reads the profiles from
+ * the .dcp file for every sequence: src/server/scan.c:227-258, profile_reader.c.) */
+#define DCP_DB_EXPAND_ON_HOST 1
+#define DCP_DB_ONE_LAYOUT 2
 int dcp_gpu_db_upload(dcp_gpu_ctx *, dcp_profile *const *profiles,
-                      unsigned nprofiles, int expand_on_host);
+                      unsigned nprofiles, int flags);
 unsigned dcp_gpu_db_nprofiles(dcp_gpu_ctx const *);
+/* 1 when the resident DB holds one table layout (asked for or chosen). */
+int dcp_gpu_db_one_layout(dcp_gpu_ctx const *);
+/* Bytes of expanded match tables resident now (the row-sweep layout of a
+ * two-layout DB appears with the first scan that needs it). */
+uint64_t dcp_gpu_db_table_bytes(dcp_gpu_ctx const *);
 /* Copy profile p's expanded match table back: out [1364][core_size]. */
 int dcp_gpu_db_fetch_match_table(dcp_gpu_ctx *, unsigned p, float *out);
 

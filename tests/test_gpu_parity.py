@@ -712,6 +712,69 @@ def test_profiles_sharing_a_wavefront_bit_exact(dcp, oracle32, scanner, nsmall):
     assert same_bits(qn, rn) and same_bits(qa, ra)
 
 
+@pytest.mark.parametrize("on_host", [False, True])
+def test_one_table_layout_bit_exact(dcp, oracle32, scanner, on_host):
+    """DCP_DB_ONE_LAYOUT (include/dcp_gpu.h): only the row-sweep tables [1364][ldk] are resident and the query-lane
+    kernels gather each 8-node tile's LDS image from them (stage_tile_image<G, true>) instead of copying a stored
+    image.  Core sizes at both ends of every tile (8 k - 1, 8 k, 8 k + 1), of the row classes (63 / 64 / 65 R nodes: a
+    row with no, one, several padding columns), profiles sharing their rows four / two at a time (column views with a
+    row length that is not their own), a flagged profile, one of several wavefronts; 1 .. 300 queries so that the
+    three query-lane kernels all run (64-query wavefronts, one stage, two stages): every kernel gives the bits of
+    the two-layout DB and of the oracle's float32 recursion on the product's tables, and the same hit list; the
+    tables take less than 0.6 of the two layouts' bytes."""
+    rng = np.random.default_rng(4100 + int(on_host))
+    cfg = dcp.ProteinCfg(ENTRY_DIST_OCCUPANCY, 0.01)
+    sizes = [1, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33, 63, 64, 65, 71, 72, 73, 127, 128, 129, 191, 192, 193, 255, 256, 257,
+             319, 320, 383, 384, 385, 512, 513, 700]
+    params = [pfam_like_params(rng, M) for M in sizes]
+    null, match, trans = pfam_like_params(rng, 44)  # flagged: positive MD / DD (never grouped, pairs go to the row sweep)
+    trans = trans.copy()
+    trans[1:44, 2] = np.float32(0.7)
+    trans[1:44, 6] = np.float32(0.4)
+    params.append((null, match, trans))
+    sizes.append(44)
+    profiles = [dcp.ProteinProfile.from_params(*prm, cfg) for prm in params]
+    oprofs = {p: oracle32.new(*params[p], ENTRY_DIST_OCCUPANCY, 0.01) for p in (11, 20, 30)}
+    for pr in profiles:
+        prof_eps[id(pr)] = cfg.epsilon
+    for nseq in (1, 70, 300):
+        seqs = rand_seqs(rng, nseq, 1, 260)
+        seqs[0] = planted_query(rng, oprofs[11], sizes[11], flank=9)
+        if nseq > 1:
+            seqs[5] = planted_query(rng, oprofs[20], sizes[20], flank=3)
+            seqs[nseq - 1] = planted_query(rng, oprofs[30], sizes[30], flank=12)
+        results = {}
+        for one in (False, True):
+            scanner.upload_db(profiles, expand_on_host=on_host, one_layout=one)
+            assert scanner.one_layout == one
+            scanner.upload_seqs(seqs)
+            for name, k in (("auto", dcp.KERNEL_AUTO), ("rowsweep", dcp.KERNEL_ROWSWEEP), ("qlane", dcp.KERNEL_QLANE),
+                            ("qlane2", dcp.KERNEL_QLANE2)):
+                scanner.scan(True, False, 10.0, kernel=k)
+                n, a = scanner.scores()
+                results[(one, name)] = (n.copy(), a.copy(), np.sort(scanner.hits(), order=["seq_idx", "profile_idx"]))
+            if one:
+                one_bytes = scanner.table_bytes
+            else:
+                two_bytes = scanner.table_bytes  # both layouts are there by now: the row sweep has run
+        assert one_bytes < 0.6 * two_bytes, (one_bytes, two_bytes)
+        # the oracle on the product's tables (read back from the one-layout DB, which is the resident one now)
+        on, oa = oracle_dp_on_product_tables(dcp, oracle32, scanner, profiles, seqs, True, False, on_host)
+        rn, ra, rh = results[(False, "rowsweep")]
+        assert same_bits(rn, on) and same_bits(ra, oa), nseq
+        assert {(0, 11)} <= {(int(h["seq_idx"]), int(h["profile_idx"])) for h in rh}
+        for key, (n, a, h) in results.items():
+            assert same_bits(n, rn) and same_bits(a, ra), (key, nseq)
+            assert np.array_equal(h, rh), (key, nseq)
+    # the traceback works on the same tables (the flagged profile's gains on its delete transitions leave it no bounded
+    # best path: its hits are refused alike on either DB)
+    sel = rh[rh["profile_idx"] != len(sizes) - 1][:4]
+    assert len(sel) > 0
+    paths, alt = scanner.trace_paths(sel, True, False)
+    for h, path, a in zip(sel, paths, alt):
+        assert len(path) > 0 and np.float32(a) == h["alt_loglik"]
+
+
 @pytest.mark.parametrize("stage,waves,prefetch2", [(0, 4, 0), (20, 4, 0), (84, 8, 0), (20, 16, 1)])
 def test_one_profile_kernels_on_shared_tables(dcp, oracle32, hooks_scanner, stage, waves, prefetch2):
     """The one-profile kernels of the two smallest classes (what the 65 .. 128-node class runs from 96 queries on) read

@@ -11,7 +11,7 @@ queries of mixed lengths (1 nt .. a few kbp, now and then tens of kbp) with a fe
   * with the automatic kernel choice, the row sweep, both query-lane kernels (shipped library), and
   * with a random forced row-sweep variant of the tests' -DDCP_TEST_HOOKS build: rows staged in LDS, wavefronts per
     block, two-row prefetch, segment-major sweep on/off, K profiles per wavefront on/off, a tiny column budget, a tiny
-    redo-list capacity.
+    redo-list capacity; in half of the rounds on a one-layout DB (DCP_DB_ONE_LAYOUT), where the query-lane kernels run too.
 
 All scans must give the same bits and the same hit list; a sample of pairs bounded by --oracle-cells (the long pairs
 are drawn with the same probability as the short ones) must equal the oracle's float32 recursion on the product's own
@@ -133,9 +133,15 @@ def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool, big_every=0):
     mp = int(rng.integers(0, 3))
     colb = int(rng.choice([0, 0, 200 << 10, 1 << 20]))
     cap = int(rng.choice([0, 0, 1, 7]))
-    hk.upload_db(profiles, expand_on_host=on_host)
+    one = bool(rng.random() < 0.5)  # DCP_DB_ONE_LAYOUT: the query-lane kernels gather their tile images from the row-sweep tables
+    hk.upload_db(profiles, expand_on_host=on_host, one_layout=one)
     hk.upload_seqs(seqs)
     try:
+        if one:
+            for name, k in (("auto", dcp.KERNEL_AUTO), ("qlane", dcp.KERNEL_QLANE), ("qlane2", dcp.KERNEL_QLANE2)):
+                hk.scan(multi, h3, 10.0, kernel=k)
+                n, a = hk.scores()
+                results[f"{name}[one layout]"] = (n.copy(), a.copy(), hk.hits().copy())
         hk.test_set_rowsweep_variant(stage, waves | (pf2 << 16) | (seg << 24) | (mp << 26))
         hk.test_set_seg_col_bytes(colb)
         hk.scan(multi, h3, 10.0, kernel=dcp.KERNEL_ROWSWEEP)
@@ -242,7 +248,7 @@ def one_round(dcp, oracle32, sc, hk, seed, oracle_cells, pool, big_every=0):
         print(f"HIT LIST != LRT FILTER ({len(got)} vs {len(want)})\n  {shape}", flush=True)
         return False, 0
     print(f"ok  {shape}; {len(results)} scans agree, {len(chosen)} pairs ({cells / 1e6:.1f} Mcell) == oracle, {len(rh)} hits, {traced} paths traced twice, "
-          f"{list(results)[-1] if cap else list(results)[4]}", flush=True)
+          f"{list(results)[-1] if cap else list(results)[7 if one else 4]}{' one-layout' if one else ''}", flush=True)
     return True, len(chosen)
 
 
